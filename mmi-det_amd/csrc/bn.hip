@@ -1,0 +1,321 @@
+// Training-mode BatchNorm + activation (+ residual) over NHWC rows, forward and backward.  HBM-bound kernels:
+// 16-byte lane accesses along the contiguous channel axis, per-channel reductions as (rows-chunk x channel) partials
+// that a tiny second kernel folds in fp64 (deterministic, no atomics, no memset).
+//
+// Replaces nn.BatchNorm2d + SiLU/LeakyReLU(0.1) (+ Bottleneck/CEM residual add) of the reference:
+// models/common.py:116-122, 613, 766-767, 774-775, 799; eps/momentum from utils/torch_utils.py:149-151.
+#include "common.h"
+
+namespace {
+
+// partials[part][2][C] (fp32) -> mean / invstd, running-stat update.  One block = 64 channels x 4 part-lanes.
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double rows, int C, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   int64_t* __restrict__ nbt, float* __restrict__ mean_invstd) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int p = pl; p < nparts; p += 4) {
+      s1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
+      s2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
+    }
+  }
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  if (pl == 0 && c < C) {
+    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    const double mean = s1 / rows;
+    double var = s2 / rows - mean * mean;  // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    mean_invstd[c] = (float)mean;
+    mean_invstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      const double unb = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps,
+                                     float* __restrict__ mean_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean_invstd[c] = rm[c];
+    mean_invstd[C + c] = 1.0f / sqrtf(rv[c] + eps);
+  }
+}
+
+template <int V>
+struct Vec {
+  float v[V];
+};
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const float* p) {
+  Vec<V> r;
+  if (V == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r.v[0] = t[0]; r.v[1 % V] = t[1]; r.v[2 % V] = t[2]; r.v[3 % V] = t[3];
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
+  if (V == 4) {
+    f32x4 t = {r.v[0], r.v[1 % V], r.v[2 % V], r.v[3 % V]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  } else {
+    p[0] = r.v[0];
+  }
+}
+
+template <int V>
+__global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mi,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo,
+                                  int64_t rows, int C, int act) {
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cv;
+    const int c = (int)(e - r * cv) * V;
+    const Vec<V> yy = ldv<V>(y + r * ldy + c), m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c),
+                 b = ldv<V>(beta + c);
+    Vec<V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.v[k] = act_fwd((yy.v[k] - m.v[k]) * is.v[k] * g.v[k] + b.v[k], act);
+    if (res != nullptr) {
+      const Vec<V> rr = ldv<V>(res + r * ldr + c);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o.v[k] += rr.v[k];
+    }
+    stv<V>(out + r * ldo + c, o);
+  }
+}
+
+// backward pass 1: block = (64-channel group, rows part); threads = (64/V channel lanes) x row lanes
+template <int V>
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
+                                     const float* __restrict__ mi, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ partials, int64_t rows, int C,
+                                     int act, int64_t rows_per_part) {
+  constexpr int CL = 64 / V, RL = 256 / CL;
+  __shared__ float red[2][RL][64];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c = blockIdx.x * 64 + cl * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_part;
+  const int64_t r1 = min(r0 + rows_per_part, rows);
+  float s1[V], s2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+  if (c < C) {
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(dout + r * ldd + c);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (yy.v[k] - m.v[k]) * is.v[k];
+        const float dz = dd.v[k] * act_grad(xh * g.v[k] + b.v[k], act);
+        s1[k] += dz;
+        s2[k] += dz * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    red[0][rl][cl * V + k] = s1[k];
+    red[1][rl][cl * V + k] = s2[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int s = threadIdx.x >> 6, cc = threadIdx.x & 63;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) acc += red[s][i][cc];
+    const int col = blockIdx.x * 64 + cc;
+    if (col < C) partials[((int64_t)blockIdx.y * 2 + s) * C + col] = acc;
+  }
+}
+
+// partials -> dbeta (= sum dz), dgamma (= sum dz*xhat)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int p = pl; p < nparts; p += 4) {
+      s1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
+      s2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
+    }
+  }
+  red[0][pl][cl] = s1;
+  red[1][pl][cl] = s2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    dbeta[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    dgamma[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+  }
+}
+
+template <int V>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
+                                    const float* __restrict__ mi, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float* __restrict__ dy, int lddy, int64_t rows, int C,
+                                    int act, int frozen) {
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  const float inv_rows = 1.0f / (float)rows;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cv;
+    const int c = (int)(e - r * cv) * V;
+    const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(dout + r * ldd + c), m = ldv<V>(mi + c),
+                 is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c), dg = ldv<V>(dgamma + c),
+                 db = ldv<V>(dbeta + c);
+    Vec<V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xh = (yy.v[k] - m.v[k]) * is.v[k];
+      const float dz = dd.v[k] * act_grad(xh * g.v[k] + b.v[k], act);
+      const float t = frozen ? dz : dz - db.v[k] * inv_rows - xh * dg.v[k] * inv_rows;
+      o.v[k] = g.v[k] * is.v[k] * t;
+    }
+    stv<V>(dy + r * lddy + c, o);
+  }
+}
+
+// column sums: block = (64 channels, rows part); 64 channel lanes x 4 row lanes
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ldx, int64_t rows, int C,
+                                      float* __restrict__ partials, int64_t rows_per_part) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_part, r1 = min(r0 + rows_per_part, rows);
+  float s = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += x[r * ldx + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) partials[(int64_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += (double)partials[(int64_t)p * C + c];
+  out[c] = (float)s;
+}
+
+inline int ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  if (C % 4) return false;
+  for (int l : lds)
+    if (l % 4) return false;
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int mmi_bn_finalize(const float* partials, int nparts, int64_t rows, int C, float eps, float momentum,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* mean_invstd, void* stream) {
+  MMI_CHECK_ARG(partials && mean_invstd && nparts > 0 && rows > 0 && C > 0, "mmi_bn_finalize: bad arguments");
+  MMI_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mmi_bn_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nparts,
+                     (double)rows, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_invstd);
+  MMI_CHECK_LAUNCH("mmi_bn_finalize");
+  return MMI_OK;
+}
+
+extern "C" int mmi_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                                 float* mean_invstd, void* stream) {
+  MMI_CHECK_ARG(running_mean && running_var && mean_invstd && C > 0, "mmi_bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, C, eps, mean_invstd);
+  MMI_CHECK_LAUNCH("mmi_bn_eval_stats");
+  return MMI_OK;
+}
+
+extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                              const float* residual, int ldr, float* out, int ldo, int64_t rows, int C, int act,
+                              void* stream) {
+  MMI_CHECK_ARG(y && mean_invstd && gamma && beta && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
+  MMI_CHECK_ARG(ldy >= C && ldo >= C && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual, mean_invstd, gamma, beta}))
+    hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, y, ldy, mean_invstd, gamma,
+                       beta, residual, ldr, out, ldo, rows, C, act);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta,
+                       residual, ldr, out, ldo, rows, C, act);
+  MMI_CHECK_LAUNCH("mmi_bn_act_fwd");
+  return MMI_OK;
+}
+
+extern "C" int mmi_bn_bwd_parts(int64_t rows) {
+  int64_t p = (rows + 127) / 128;
+  return (int)(p > 1024 ? 1024 : (p < 1 ? 1 : p));
+}
+
+extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout, int ldd, const float* mean_invstd,
+                                     const float* gamma, const float* beta, float* partials, int64_t rows, int C,
+                                     int act, void* stream) {
+  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && rows > 0 && C > 0, "mmi_bn_act_bwd_reduce: bad arguments");
+  const int nparts = mmi_bn_bwd_parts(rows);
+  const int64_t rpp = (rows + nparts - 1) / nparts;
+  const dim3 grid(cdiv(C, 64), nparts);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, beta, partials,
+                       rows, C, act, rpp);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, beta, partials,
+                       rows, C, act, rpp);
+  MMI_CHECK_LAUNCH("mmi_bn_act_bwd_reduce");
+  return MMI_OK;
+}
+
+extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, const float* mean_invstd,
+                                    const float* gamma, const float* beta, const float* partials, int nparts, float* dy,
+                                    int lddy, float* dgamma, float* dbeta, int64_t rows, int C, int act, int frozen,
+                                    void* stream) {
+  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && dy && dgamma && dbeta && rows > 0 && C > 0,
+                "mmi_bn_act_bwd_apply: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta);
+  MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
+  if (vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta}))
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, y, ldy, dout, ldd,
+                       mean_invstd, gamma, beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd,
+                       gamma, beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen);
+  MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply");
+  return MMI_OK;
+}
+
+extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {
+  MMI_CHECK_ARG(x && partials && out && rows > 0 && C > 0 && ldx >= C, "mmi_colsum: bad arguments");
+  const int nparts = mmi_bn_bwd_parts(rows);
+  const int64_t rpp = (rows + nparts - 1) / nparts;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, s, x, ldx, rows, C, partials, rpp);
+  MMI_CHECK_LAUNCH("mmi_colsum");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, partials, nparts, C, out);
+  MMI_CHECK_LAUNCH("mmi_colsum(finalize)");
+  return MMI_OK;
+}

@@ -1,0 +1,57 @@
+// Shared helpers for libmmidet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <initializer_list>
+
+#include "../../include/mmidet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void mmi_set_error(const char* fmt, ...);
+
+#define MMI_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      mmi_set_error(__VA_ARGS__);     \
+      return MMI_ERR_ARG;             \
+    }                                 \
+  } while (0)
+
+#define MMI_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      mmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return MMI_ERR_LAUNCH;                                               \
+    }                                                                      \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (observed round-robin), so give
+// each XCD a contiguous chunk of the tile sequence; neighbouring tiles (same activation rows, all output-channel
+// tiles) then hit the same 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == MMI_ACT_SILU) return z / (1.0f + expf(-z));
+  if (act == MMI_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == MMI_ACT_SILU) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+  }
+  if (act == MMI_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;
+  return 1.0f;
+}

@@ -1,0 +1,343 @@
+// Layout conversion, adds, strided copies, nearest upsample, SPP max-pools.  All HBM-bound: channel axis contiguous,
+// 16-byte lane accesses wherever strides allow, grid-stride loops sized to fill 256 CUs.
+//
+// Replaces: the /255 split views -> NHWC (train.py:743-745 boundary), Focus slicing (models/common.py:708),
+// Add/Add2/Concat (common.py:914-935, 740-748), nn.Upsample nearest x2 (YAML head), SPP max-pools (common.py:681-693),
+// the Detect view/permute (models/yolo_test.py:54-55).
+#include "common.h"
+
+namespace {
+
+inline int ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+#define GRID_STRIDE(e, total) \
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (total); e += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                    float* __restrict__ y, int N, int C, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  GRID_STRIDE(e, total) {
+    const int w = (int)(e % W);
+    const int64_t t = e / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* src = x + n * sn + h * sh + w * sw;
+    float* dst = y + e * C;
+    for (int c = 0; c < C; ++c) dst[c] = src[c * sc];
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W) {
+  const int64_t total = (int64_t)N * C * H * W;
+  GRID_STRIDE(e, total) {
+    const int w = (int)(e % W);
+    int64_t t = e / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    y[e] = x[(((int64_t)n * H + h) * W + w) * C + c];
+  }
+}
+
+// y(N,H/2,W/2,4C): channel q*C+c <- x(n, 2*oh+dy, 2*ow+dx, c), q = dy + 2*dx   (common.py:708 slice order)
+__global__ void s2d_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int inverse) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * 4 * C;
+  GRID_STRIDE(e, total) {
+    const int cc = (int)(e % (4 * C));
+    int64_t t = e / (4 * C);
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int q = cc / C, c = cc - q * C;
+    const int dy = q & 1, dx = q >> 1;
+    const int64_t xi = (((int64_t)n * H + 2 * oh + dy) * W + 2 * ow + dx) * C + c;
+    if (inverse) out[xi] = in[e];  // in: (N,H/2,W/2,4C) gradient, out: (N,H,W,C) gradient
+    else out[e] = in[xi];
+  }
+}
+
+template <int V>
+__global__ void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                           float* __restrict__ o, int ldo, int64_t rows, int C) {
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  GRID_STRIDE(e, total) {
+    const int64_t r = e / cv;
+    const int c = (int)(e - r * cv) * V;
+    if (V == 4) {
+      const f32x4 va = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(b + r * ldb + c);
+      *reinterpret_cast<f32x4*>(o + r * ldo + c) = va + vb;
+    } else {
+      o[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+    }
+  }
+}
+
+template <int V>
+__global__ void copy2d_kernel(const float* __restrict__ a, int lda, float* __restrict__ o, int ldo, int64_t rows, int C) {
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  GRID_STRIDE(e, total) {
+    const int64_t r = e / cv;
+    const int c = (int)(e - r * cv) * V;
+    if (V == 4) *reinterpret_cast<f32x4*>(o + r * ldo + c) = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+    else o[r * ldo + c] = a[r * lda + c];
+  }
+}
+
+template <int V>
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int cv = C / V, Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * Ho * Wo * cv;
+  GRID_STRIDE(e, total) {
+    const int c = (int)(e % cv) * V;
+    int64_t t = e / cv;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* src = x + (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C + c;
+    float* dst = y + (((int64_t)n * Ho + oh) * Wo + ow) * C + c;
+    if (V == 4) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+    else dst[0] = src[0];
+  }
+}
+
+template <int V>
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+  const int cv = C / V, Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * H * W * cv;
+  GRID_STRIDE(e, total) {
+    const int c = (int)(e % cv) * V;
+    int64_t t = e / cv;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* s00 = dy + (((int64_t)n * Ho + 2 * h) * Wo + 2 * w) * C + c;
+    const float* s10 = s00 + (int64_t)Wo * C;
+    float* dst = dx + (((int64_t)n * H + h) * W + w) * C + c;
+    if (V == 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s00), b = *reinterpret_cast<const f32x4*>(s00 + C),
+                  cc = *reinterpret_cast<const f32x4*>(s10), d = *reinterpret_cast<const f32x4*>(s10 + C);
+      *reinterpret_cast<f32x4*>(dst) = (a + b) + (cc + d);
+    } else {
+      dst[0] = (s00[0] + s00[C]) + (s10[0] + s10[C]);
+    }
+  }
+}
+
+// 5x5 stride-1 max-pool with implicit -inf padding; src/dst are channel slices (row strides lds/ldd)
+template <int V>
+__global__ void maxpool5_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int N, int H,
+                                int W, int C) {
+  const int cv = C / V;
+  const int64_t total = (int64_t)N * H * W * cv;
+  GRID_STRIDE(e, total) {
+    const int c = (int)(e % cv) * V;
+    int64_t t = e / cv;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+    for (int dh = -2; dh <= 2; ++dh) {
+      const int hh = h + dh;
+      if (hh < 0 || hh >= H) continue;
+      for (int dw = -2; dw <= 2; ++dw) {
+        const int ww = w + dw;
+        if (ww < 0 || ww >= W) continue;
+        const float* p = src + (((int64_t)n * H + hh) * W + ww) * lds + c;
+        if (V == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+          for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], v[k]);
+        } else {
+          m[0] = fmaxf(m[0], p[0]);
+        }
+      }
+    }
+    float* o = dst + (((int64_t)n * H + h) * W + w) * ldd + c;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = m[k];
+  }
+}
+
+// SPP backward: thread = one (pixel, channel, pool k in {5,9,13}); routes dcat[..,(1+k)C+c] to the first arg-max of the
+// window of x (row-major scan, strict >, as ATen's max_pool2d) with a float atomic (few colliding adders).
+__global__ void spp_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat, int ldd,
+                               float* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+  const int64_t total = (int64_t)N * H * W * C * 3;
+  GRID_STRIDE(e, total) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int pk = (int)(t % 3);
+    t /= 3;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const int rad = 2 + 2 * pk;  // 5,9,13 -> radius 2,4,6
+    float best = -INFINITY;
+    int bh = -1, bw = -1;
+    for (int hh = max(h - rad, 0); hh <= min(h + rad, H - 1); ++hh)
+      for (int ww = max(w - rad, 0); ww <= min(w + rad, W - 1); ++ww) {
+        const float v = x[(((int64_t)n * H + hh) * W + ww) * ldx + c];
+        if (v > best || bh < 0) {
+          best = v;
+          bh = hh;
+          bw = ww;
+        }
+      }
+    const float g = dcat[(((int64_t)n * H + h) * W + w) * ldd + (1 + pk) * C + c];
+    atomicAdd(dx + (((int64_t)n * H + bh) * W + bw) * lddx + c, g);
+  }
+}
+
+// Detect head: in (B, P=ny*nx, na*no) -> out (B, na, P, no)   [inverse: the gradient goes the other way]
+__global__ void head_permute_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int na, int no,
+                                    int P, int inverse) {
+  const int64_t total = (int64_t)B * na * P * no;
+  GRID_STRIDE(e, total) {
+    const int o = (int)(e % no);
+    int64_t t = e / no;
+    const int pix = (int)(t % P);
+    t /= P;
+    const int a = (int)(t % na);
+    const int b = (int)(t / na);
+    const int64_t ii = (((int64_t)b * P + pix) * na + a) * no + o;
+    if (inverse) out[ii] = in[e];
+    else out[e] = in[ii];
+  }
+}
+
+inline bool vec4(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  if (C % 4) return false;
+  for (int l : lds)
+    if (l % 4) return false;
+  for (const void* p : ptrs)
+    if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int mmi_nchw_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int N, int C,
+                                int H, int W, void* stream) {
+  MMI_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "mmi_nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, sn,
+                     sc, sh, sw, y, N, C, H, W);
+  MMI_CHECK_LAUNCH("mmi_nchw_to_nhwc");
+  return MMI_OK;
+}
+
+extern "C" int mmi_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream) {
+  MMI_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "mmi_nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, N, C, H, W);
+  MMI_CHECK_LAUNCH("mmi_nhwc_to_nchw");
+  return MMI_OK;
+}
+
+extern "C" int mmi_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream) {
+  MMI_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "mmi_space_to_depth: bad arguments");
+  hipLaunchKernelGGL(s2d_kernel, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, out, N, H, W,
+                     C, inverse);
+  MMI_CHECK_LAUNCH("mmi_space_to_depth");
+  return MMI_OK;
+}
+
+extern "C" int mmi_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t rows, int C,
+                       void* stream) {
+  MMI_CHECK_ARG(a && b && out && rows > 0 && C > 0 && lda >= C && ldb >= C && ldo >= C, "mmi_add: bad arguments");
+  if (vec4(C, {lda, ldb, ldo}, {a, b, out}))
+    hipLaunchKernelGGL(add_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       out, ldo, rows, C);
+  else
+    hipLaunchKernelGGL(add_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out,
+                       ldo, rows, C);
+  MMI_CHECK_LAUNCH("mmi_add");
+  return MMI_OK;
+}
+
+extern "C" int mmi_copy2d(const float* in, int ldi, float* out, int ldo, int64_t rows, int C, void* stream) {
+  MMI_CHECK_ARG(in && out && rows > 0 && C > 0 && ldi >= C && ldo >= C, "mmi_copy2d: bad arguments");
+  if (vec4(C, {ldi, ldo}, {in, out}))
+    hipLaunchKernelGGL(copy2d_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, in, ldi, out,
+                       ldo, rows, C);
+  else
+    hipLaunchKernelGGL(copy2d_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, in, ldi, out, ldo,
+                       rows, C);
+  MMI_CHECK_LAUNCH("mmi_copy2d");
+  return MMI_OK;
+}
+
+extern "C" int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "mmi_upsample2x: bad arguments");
+  if (vec4(C, {}, {x, y}))
+    hipLaunchKernelGGL(upsample2x_kernel<4>, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, N, H, W, C);
+  else
+    hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(ew_blocks((int64_t)N * H * W * C * 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, H, W, C);
+  MMI_CHECK_LAUNCH("mmi_upsample2x");
+  return MMI_OK;
+}
+
+extern "C" int mmi_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(dy && dx && N > 0 && C > 0 && H > 0 && W > 0, "mmi_upsample2x_bwd: bad arguments");
+  if (vec4(C, {}, {dy, dx}))
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<4>, dim3(ew_blocks((int64_t)N * H * W * C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, N, H, W, C);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<1>, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0,
+                       (hipStream_t)stream, dy, dx, N, H, W, C);
+  MMI_CHECK_LAUNCH("mmi_upsample2x_bwd");
+  return MMI_OK;
+}
+
+extern "C" int mmi_spp_pool_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(x && out && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && ldo >= 4 * C, "mmi_spp_pool_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = (int64_t)N * H * W;
+  if (int e = mmi_copy2d(x, ldx, out, ldo, rows, C, stream)) return e;
+  const bool v = vec4(C, {ldo}, {out});
+  for (int k = 0; k < 3; ++k) {  // mp5 = P(x), mp9 = P(mp5), mp13 = P(mp9)
+    const float* src = out + (int64_t)k * C;
+    float* dst = out + (int64_t)(k + 1) * C;
+    if (v)
+      hipLaunchKernelGGL(maxpool5_kernel<4>, dim3(ew_blocks(rows * C / 4)), dim3(256), 0, s, src, ldo, dst, ldo, N, H, W, C);
+    else
+      hipLaunchKernelGGL(maxpool5_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, src, ldo, dst, ldo, N, H, W, C);
+    MMI_CHECK_LAUNCH("mmi_spp_pool_fwd");
+  }
+  return MMI_OK;
+}
+
+extern "C" int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int ldd, float* dx, int lddx, int N, int H,
+                                int W, int C, void* stream) {
+  MMI_CHECK_ARG(x && dcat && dx && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && ldd >= 4 * C && lddx >= C,
+                "mmi_spp_pool_bwd: bad arguments");
+  const int64_t rows = (int64_t)N * H * W;
+  if (int e = mmi_copy2d(dcat, ldd, dx, lddx, rows, C, stream)) return e;
+  hipLaunchKernelGGL(spp_bwd_kernel, dim3(ew_blocks(rows * C * 3)), dim3(256), 0, (hipStream_t)stream, x, ldx, dcat, ldd,
+                     dx, lddx, N, H, W, C);
+  MMI_CHECK_LAUNCH("mmi_spp_pool_bwd");
+  return MMI_OK;
+}
+
+extern "C" int mmi_head_permute(const float* in, float* out, int B, int na, int no, int P, int inverse, void* stream) {
+  MMI_CHECK_ARG(in && out && B > 0 && na > 0 && no > 0 && P > 0, "mmi_head_permute: bad arguments");
+  hipLaunchKernelGGL(head_permute_kernel, dim3(ew_blocks((int64_t)B * na * P * no)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, B, na, no, P, inverse);
+  MMI_CHECK_LAUNCH("mmi_head_permute");
+  return MMI_OK;
+}

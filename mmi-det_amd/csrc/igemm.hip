@@ -1,0 +1,583 @@
+// fp32-MFMA implicit-GEMM convolution for gfx950: forward, data-gradient, weight-gradient.
+//
+// Replaces (SURVEY.md §8a rows 4,5,6,9,11,16) the ATen conv2d / linear forward+backward reached from
+// models/common.py:114,764,772,333,337,1167-1170,1254,1257 and models/yolo_test.py:44 of the reference.
+//
+// Design (MI355X-first, not a cuDNN-style port):
+//  * activations NHWC, weights OHWI  -> the GEMM K axis (tap, channel) is contiguous in both operands, every global
+//    access is a 16-byte lane access over 128-byte row segments;
+//  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD); 256-thread workgroups = 4 waves in a 2x2 grid, each wave
+//    owning (BM/2)x(BN/2) of the BMxBN tile as 32x32 accumulator tiles;
+//  * A/B K-slabs of 32 staged through LDS, double buffered, one barrier per K-step; next slab's global loads are issued
+//    before the MFMA block so HBM/L2 latency hides behind 4096 cycles of matrix work;
+//  * LDS rows padded 32->36 floats so the ds_read_b128 operand fetches are bank-conflict-free; one b128 per lane
+//    feeds FOUR k-steps (the K order inside a slab is permuted identically for A and B, which a GEMM sum allows);
+//  * XCD-aware tile order: all output-channel tiles of a pixel tile run on one XCD (shared 4 MiB L2);
+//  * epilogue fuses bias and the BatchNorm batch-statistics partial sums (no extra pass over y for mean/var).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_PAD = BK + 4;  // floats per [row][k] LDS row
+
+struct IgemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  float* stat_part;
+  int M, Ncol, Kc, KH, KW, P, Q, Hs, Ws, lda, ldc, stride, pad, Ktot, ldb, mtiles, ntiles;
+};
+
+// one row of the A tile as seen by a loader thread
+struct RowInfo {
+  int64_t base;  // source-image pixel base (img * Hs * Ws); -1 -> row out of range
+  int ph, qw;    // fwd: p*stride-pad ; dgrad: p+pad
+};
+
+template <bool DGRAD>
+__device__ __forceinline__ bool src_pixel(const IgemmP& p, const RowInfo& r, int kh, int kw, int64_t& pix) {
+  int ih, iw;
+  if (!DGRAD) {
+    ih = r.ph + kh;
+    iw = r.qw + kw;
+  } else {
+    int th = r.ph - kh, tw = r.qw - kw;
+    if (th < 0 || tw < 0) return false;
+    if (p.stride == 2) {
+      if ((th | tw) & 1) return false;
+      ih = th >> 1;
+      iw = tw >> 1;
+    } else {
+      ih = th;
+      iw = tw;
+    }
+  }
+  if (r.base < 0 || ih < 0 || iw < 0 || ih >= p.Hs || iw >= p.Ws) return false;
+  pix = r.base + (int64_t)ih * p.Ws + iw;
+  return true;
+}
+
+template <bool DGRAD, bool VEC>
+__device__ __forceinline__ f32x4 load_a(const IgemmP& p, const RowInfo& r, int k) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (k < p.Ktot) {
+      const int tap = k / p.Kc, c = k - tap * p.Kc;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      int64_t pix;
+      if (src_pixel<DGRAD>(p, r, kh, kw, pix)) v = *reinterpret_cast<const f32x4*>(p.A + pix * p.lda + c);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ke = k + e;
+      if (ke < p.Ktot) {
+        const int tap = ke / p.Kc, c = ke - tap * p.Kc;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        int64_t pix;
+        if (src_pixel<DGRAD>(p, r, kh, kw, pix)) v[e] = p.A[pix * p.lda + c];
+      }
+    }
+  }
+  return v;
+}
+
+// fwd weights: B[n][k], k contiguous
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_b_nk(const IgemmP& p, int n, int k) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.Ncol) {
+    const float* src = p.B + (int64_t)n * p.ldb + k;
+    if (VEC) {
+      if (k < p.Ktot) v = *reinterpret_cast<const f32x4*>(src);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < p.Ktot) v[e] = src[e];
+    }
+  }
+  return v;
+}
+
+// dgrad weights: B[k=(tap,co)][n=ci] = W[co][tap][ci], n contiguous
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_b_kn(const IgemmP& p, int k, int n) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (k < p.Ktot) {
+    const int tap = k / p.Kc, co = k - tap * p.Kc;
+    const float* src = p.B + (int64_t)co * p.ldb + (int64_t)tap * p.Ncol + n;
+    if (VEC) {
+      if (n < p.Ncol) v = *reinterpret_cast<const f32x4*>(src);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.Ncol) v[e] = src[e];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, bool DGRAD, bool VEC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int RA = BM / 32;                       // A rows per loader thread
+  constexpr int A_ELEMS = BM * LDS_PAD;
+  constexpr int B_ELEMS = DGRAD ? BK * BN : BN * LDS_PAD;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  constexpr int RB = BN / 32;                       // fwd: B rows per loader thread
+  constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
+  __shared__ __align__(16) float smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kq = (t & 7) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
+  const int lrow = t >> 3;     // 0..31
+
+  RowInfo rows[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int pq = p.P * p.Q;
+      const int img = m / pq, rem = m - img * pq;
+      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      rows[i].base = (int64_t)img * p.Hs * p.Ws;
+      rows[i].ph = DGRAD ? pp + p.pad : pp * p.stride - p.pad;
+      rows[i].qw = DGRAD ? qq + p.pad : qq * p.stride - p.pad;
+    } else {
+      rows[i].base = -1;
+      rows[i].ph = rows[i].qw = 0;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[RA];
+  f32x4 rb[DGRAD ? KB_IT : RB];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ra[i] = load_a<DGRAD, VEC>(p, rows[i], k0 + kq);
+    if (!DGRAD) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0 + kq);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KB_IT; ++i) rb[i] = load_b_kn<VEC>(p, k0 + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+    }
+  };
+  auto lstore = [&](int stage) {
+    float* As = smem + stage * STAGE;
+    float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_PAD + kq) = ra[i];
+    if (!DGRAD) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_PAD + kq) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[i];
+    }
+  };
+
+  const int nk = (p.Ktot + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int ks = 0; ks < nk; ++ks) {
+    if (ks + 1 < nk) gload((ks + 1) * BK);
+    const float* As = smem + (ks & 1) * STAGE;
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+      if (!DGRAD) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[j][e] = Bs[(g * 8 + lh * 4 + e) * BN + wn * WN + j * 32 + l31];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l31;
+    const bool cok = col < p.Ncol;
+    const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[i][j][r] + bv;
+        s1 += v;
+        s2 += v * v;
+        if (cok && row < p.M) p.C[(int64_t)row * p.ldc + col] = v;
+      }
+    }
+    if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      float* red = smem;  // [2 stats][2 wm][BN]; safe: the K loop ended with a barrier
+      if (lh == 0) {
+        red[(0 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s1;
+        red[(1 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s2;
+      }
+    }
+  }
+  if (p.stat_part != nullptr) {
+    __syncthreads();
+    for (int idx = t; idx < 2 * BN; idx += 256) {
+      const int s = idx / BN, c = idx - s * BN;
+      const int col = n0 + c;
+      if (col < p.Ncol) p.stat_part[((int64_t)mt * 2 + s) * p.Ncol + col] = smem[(s * 2 + 0) * BN + c] + smem[(s * 2 + 1) * BN + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: C[co][(tap,ci)] = sum_pix dy[pix][co] * x[gather(pix,tap)][ci]; both operands are K(pixel)-strided,
+// tiles live in LDS as [k][m] / [k][n] and the MFMA operands are conflict-free ds_read_b32.
+struct WgradP {
+  const float* DY;
+  const float* X;
+  float* OUT;  // dw, or slab base when splits > 1
+  int Mpix, Cout, Cin, KH, KW, Ho, Wo, H, W, stride, pad, ldx, ldy, Ntot, chunk, mtiles, ntiles, splits;
+  int64_t slab_stride;
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
+  constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
+  constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN, STAGE = A_ELEMS + B_ELEMS;
+  __shared__ __align__(16) float smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = blockIdx.y * p.chunk;
+  const int kend = min(kbeg + p.chunk, p.Mpix);
+
+  // A loader: float4 along co
+  const int am = m0 + (t % VA) * 4, akr = t / VA;
+  // B loader: float4 along (tap,ci): fixed per thread
+  const int bn = n0 + (t % VB) * 4, bkr = t / VB;
+  int b_kh[4], b_kw[4], b_ci[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+    const int n = bn + e;
+    b_ok[e] = n < p.Ntot;
+    const int tap = b_ok[e] ? n / p.Cin : 0;
+    b_ci[e] = n - tap * p.Cin;
+    b_kh[e] = tap / p.KW;
+    b_kw[e] = tap - b_kh[e] * p.KW;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[ITA], rb[ITB];
+  const int howo = p.Ho * p.Wo;
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) {
+      const int pix = k0 + akr + RPA * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < kend) {
+        const float* src = p.DY + (int64_t)pix * p.ldy + am;
+        if (VEC) {
+          if (am < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (am + e < p.Cout) v[e] = src[e];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) {
+      const int pix = k0 + bkr + RPB * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < kend) {
+        const int img = pix / howo, rem = pix - img * howo;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        if (VEC) {
+          const int ih = ih0 + b_kh[0], iw = iw0 + b_kw[0];
+          if (b_ok[0] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W)
+            v = *reinterpret_cast<const f32x4*>(p.X + (((int64_t)img * p.H + ih) * p.W + iw) * p.ldx + b_ci[0]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ih = ih0 + b_kh[e], iw = iw0 + b_kw[e];
+            if (b_ok[e] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W)
+              v[e] = p.X[(((int64_t)img * p.H + ih) * p.W + iw) * p.ldx + b_ci[e]];
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int stage) {
+    float* As = smem + stage * STAGE;
+    float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) *reinterpret_cast<f32x4*>(As + (akr + RPA * i) * BM + (t % VA) * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) *reinterpret_cast<f32x4*>(Bs + (bkr + RPB * i) * BN + (t % VB) * 4) = rb[i];
+  };
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (nk > 0) {
+    gload(kbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    if (ks + 1 < nk) gload(kbeg + (ks + 1) * BK);
+    const float* As = smem + (ks & 1) * STAGE;
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + lh) * BM + wm * WM + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + lh) * BN + wn * WN + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    __syncthreads();
+  }
+
+  float* out = p.OUT + (int64_t)blockIdx.y * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WN + j * 32 + l31;
+    if (col < p.Ntot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < p.Cout) out[(int64_t)row * p.Ntot + col] = acc[i][j][r];
+        }
+    }
+  }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * n + i];
+  out[i] = s;
+}
+
+struct FwdPlan {
+  int bm, bn, mtiles, ntiles;
+};
+FwdPlan plan_tiles(int64_t M, int Ncol) {
+  FwdPlan f;
+  f.bn = Ncol > 64 ? 128 : 64;
+  f.bm = 128;
+  // small problems: shrink the tile until there are >= 2 workgroups per CU (256 CUs)
+  if (f.bn == 128 && (int64_t)cdiv(M, 128) * cdiv(Ncol, 128) < 512) f.bn = 64;
+  if ((int64_t)cdiv(M, 128) * cdiv(Ncol, f.bn) < 512) f.bm = 64, f.bn = 64;
+  f.mtiles = cdiv(M, f.bm);
+  f.ntiles = cdiv(Ncol, f.bn);
+  return f;
+}
+
+template <bool DGRAD>
+int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
+  IgemmP p = p0;
+  p.mtiles = f.mtiles;
+  p.ntiles = f.ntiles;
+  const dim3 grid(f.mtiles * f.ntiles), block(256);
+#define LAUNCH(BM_, BN_, VEC_)                                                                      \
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_>), grid, block, 0, s, p)
+  if (!vec) {
+    if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
+    else LAUNCH(64, 64, false);
+  } else if (f.bm == 128 && f.bn == 128) LAUNCH(128, 128, true);
+  else if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, true);
+  else LAUNCH(64, 64, true);
+#undef LAUNCH
+  MMI_CHECK_LAUNCH(DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd");
+  return MMI_OK;
+}
+
+int check_desc(const mmi_conv_desc* d, const char* who) {
+  MMI_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  MMI_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dims", who);
+  MMI_CHECK_ARG(d->KH == d->KW && (d->KH == 1 || d->KH == 3), "%s: kernel %dx%d unsupported (1x1, 3x3)", who, d->KH, d->KW);
+  MMI_CHECK_ARG(d->stride == 1 || d->stride == 2, "%s: stride %d unsupported", who, d->stride);
+  MMI_CHECK_ARG(d->pad == d->KH / 2, "%s: pad %d != k/2", who, d->pad);
+  MMI_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                "%s: output dims (%d,%d) inconsistent", who, d->Ho, d->Wo);
+  MMI_CHECK_ARG(d->ldx >= d->Cin && d->ldy >= d->Cout, "%s: row strides smaller than channel counts", who);
+  MMI_CHECK_ARG((int64_t)d->N * d->H * d->W < (1LL << 31) && (int64_t)d->KH * d->KW * d->Cin < (1 << 24), "%s: size overflow", who);
+  return MMI_OK;
+}
+
+FwdPlan fwd_plan(const mmi_conv_desc* d, bool vec) {
+  FwdPlan f = plan_tiles((int64_t)d->N * d->Ho * d->Wo, d->Cout);
+  if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(d->Cout, 64);
+  return f;
+}
+bool fwd_vec(const mmi_conv_desc* d) { return d->Cin % 4 == 0 && d->ldx % 4 == 0; }
+
+}  // namespace
+
+extern "C" int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_fwd_row_blocks") != MMI_OK) return MMI_ERR_ARG;
+  return fwd_plan(d, fwd_vec(d)).mtiles;
+}
+
+extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
+                            const mmi_conv_desc* d, void* stream) {
+  if (int e = check_desc(d, "mmi_conv_fwd")) return e;
+  MMI_CHECK_ARG(x && w && y, "mmi_conv_fwd: null pointer");
+  MMI_CHECK_ARG(!(bias && stat_partials), "mmi_conv_fwd: bias and BN statistics are mutually exclusive");
+  const bool vec = fwd_vec(d);
+  MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mmi_conv_fwd: operands must be 16-byte aligned");
+  IgemmP p{};
+  p.A = x; p.B = w; p.C = y; p.bias = bias; p.stat_part = stat_partials;
+  p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
+  return launch_igemm<false>(p, fwd_plan(d, vec), vec, (hipStream_t)stream);
+}
+
+extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, void* stream) {
+  if (int e = check_desc(d, "mmi_conv_dgrad")) return e;
+  MMI_CHECK_ARG(dy && w && dx, "mmi_conv_dgrad: null pointer");
+  // A = dy (channels Cout), output columns = Cin
+  const bool vec = d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->Cin % 4 == 0;
+  MMI_CHECK_ARG(!vec || (((uintptr_t)dy | (uintptr_t)w) & 15) == 0, "mmi_conv_dgrad: operands must be 16-byte aligned");
+  IgemmP p{};
+  p.A = dy; p.B = w; p.C = dx; p.bias = nullptr; p.stat_part = nullptr;
+  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
+  FwdPlan f = plan_tiles(p.M, p.Ncol);
+  if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(p.Ncol, 64);
+  return launch_igemm<true>(p, f, vec, (hipStream_t)stream);
+}
+
+namespace {
+struct WgPlan {
+  int bm, bn, mtiles, ntiles, splits, chunk;
+  bool vec;
+};
+WgPlan wgrad_plan(const mmi_conv_desc* d) {
+  WgPlan g;
+  const int Ntot = d->KH * d->KW * d->Cin;
+  const int64_t Mpix = (int64_t)d->N * d->Ho * d->Wo;
+  g.vec = d->Cin % 4 == 0 && d->Cout % 4 == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0;
+  g.bm = d->Cout > 64 ? 128 : 64;
+  g.bn = Ntot > 64 ? 128 : 64;
+  if (!g.vec) g.bm = g.bn = 64;
+  g.mtiles = cdiv(d->Cout, g.bm);
+  g.ntiles = cdiv(Ntot, g.bn);
+  const int tiles = g.mtiles * g.ntiles;
+  int splits = cdiv(1024, tiles);                                   // ~4 workgroups per CU
+  const int max_splits = (int)((Mpix + 255) / 256);                 // >= 256 pixels (8 K-steps) per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;
+  g.splits = cdiv(Mpix, g.chunk);
+  return g;
+}
+}  // namespace
+
+extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_wgrad_workspace") != MMI_OK) return 0;
+  const WgPlan g = wgrad_plan(d);
+  return g.splits > 1 ? (size_t)g.splits * d->Cout * d->KH * d->KW * d->Cin * sizeof(float) : 0;
+}
+
+extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
+                              const mmi_conv_desc* d, void* stream) {
+  if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
+  MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
+  const WgPlan g = wgrad_plan(d);
+  MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
+  const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;
+  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.splits * wsize * sizeof(float))) {
+    mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)g.splits * wsize * sizeof(float));
+    return MMI_ERR_WORKSPACE;
+  }
+  WgradP p{};
+  p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? (float*)workspace : dw;
+  p.Mpix = d->N * d->Ho * d->Wo; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.H = d->H; p.W = d->W; p.stride = d->stride; p.pad = d->pad;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.Ntot = d->KH * d->KW * d->Cin; p.chunk = g.chunk;
+  p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = wsize;
+  const dim3 grid(g.mtiles * g.ntiles, g.splits), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCHW(BM_, BN_, VEC_) \
+  hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
+  if (!g.vec) LAUNCHW(64, 64, false);
+  else if (g.bm == 128 && g.bn == 128) LAUNCHW(128, 128, true);
+  else if (g.bm == 128) LAUNCHW(128, 64, true);
+  else if (g.bn == 128) LAUNCHW(64, 128, true);
+  else LAUNCHW(64, 64, true);
+#undef LAUNCHW
+  MMI_CHECK_LAUNCH("mmi_conv_wgrad");
+  if (g.splits > 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 256)), dim3(256), 0, s, (const float*)workspace, dw, wsize, g.splits);
+    MMI_CHECK_LAUNCH("mmi_conv_wgrad(reduce)");
+  }
+  return MMI_OK;
+}

@@ -1,0 +1,84 @@
+"""ctypes binding of csrc/libmmidet_hip.so (C ABI: include/mmidet_hip.h).  Fails loudly when the library is missing:
+there is no CPU/ATen fallback for any op of the hot path."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libmmidet_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('%s is missing: the HIP extension is not built (run `python __graft_entry__.py` or '
+                      '`python mmi-det_amd/mmidet_hip/build.py`); the MI355X hot path has no fallback.' % LIB_PATH)
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad', 'ldx',
+                                       'ldy')]
+
+
+P = c_void_p
+_SIGS = {
+    'mmi_version': (c_int, []),
+    'mmi_last_error': (c_char_p, []),
+    'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
+    'mmi_conv_fwd': (c_int, [P, P, P, P, P, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad': (c_int, [P, P, P, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
+    'mmi_conv_wgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
+    'mmi_bn_eval_stats': (c_int, [P, P, c_int, c_float, P, P]),
+    'mmi_bn_act_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, c_int64, c_int, c_int, P]),
+    'mmi_bn_bwd_parts': (c_int, [c_int64]),
+    'mmi_bn_act_bwd_reduce': (c_int, [P, c_int, P, c_int, P, P, P, P, c_int64, c_int, c_int, P]),
+    'mmi_bn_act_bwd_apply': (c_int, [P, c_int, P, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int64, c_int, c_int,
+                                     c_int, P]),
+    'mmi_colsum': (c_int, [P, c_int, c_int64, c_int, P, P, P]),
+    'mmi_nchw_to_nhwc': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_space_to_depth': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_head_permute': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_add': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_copy2d': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_upsample2x': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_spp_pool_fwd': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_spp_pool_bwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_build_targets': (c_int, [P, c_int, P, c_int, c_int, P, c_float, P, P, P, P, P, P]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+class MMIError(RuntimeError):
+    pass
+
+
+def _bind(name, restype, argtypes):
+    fn = getattr(_lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    if restype is not c_int or name in ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_bn_bwd_parts'):
+        return fn
+
+    def checked(*args):
+        rc = fn(*args)
+        if rc != 0:
+            raise MMIError('%s failed (%d): %s' % (name, rc, _lib.mmi_last_error().decode()))
+    checked.__name__ = name
+    return checked
+
+
+def register(sigs):
+    """Bind further entry points (other modules of this package extend the table as kernels are added)."""
+    for name, (restype, argtypes) in sigs.items():
+        _SIGS[name] = (restype, argtypes)
+        globals()[name[4:]] = _bind(name, restype, argtypes)
+    EXPORTS[:] = sorted(_SIGS)
+
+
+register(dict(_SIGS))

@@ -1,0 +1,356 @@
+"""autograd glue over the C ABI.  Activations are NHWC tensors (N,H,W,C) (or (rows,C) token matrices) whose channel
+axis is contiguous; a tensor may be a channel slice of a wider buffer (row stride ld > C).  Every function here only
+enqueues HIP kernels of libmmidet_hip.so on the current torch stream."""
+import torch
+from torch.autograd import Function
+
+from . import lib
+from .lib import ACT_LEAKY, ACT_NONE, ACT_SILU, ConvDesc  # noqa: F401
+
+_scratch = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def scratch(nfloats, device, slot=0):
+    """Grow-only fp32 workspace per (device, slot).  Safe to share: all kernels of a step run on one stream in order."""
+    key = (device, slot)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def rows_of(t):
+    """Return (tensor, ld): `tensor` is `t` (or a compacted copy) viewed as rows x C with unit channel stride and a
+    uniform row stride ld."""
+    assert t.dtype == torch.float32 and t.is_cuda, 'mmidet_hip ops need fp32 tensors on the MI355X'
+    C = t.shape[-1]
+    if t.dim() == 1:
+        return (t if t.stride(0) == 1 else t.contiguous()), C
+    ok = t.stride(-1) == 1 or C == 1
+    ld = t.stride(-2) if t.shape[-2] != 1 else C
+    if ok and t.dim() > 2:
+        expect = ld * t.shape[-2]
+        for d in range(t.dim() - 3, -1, -1):
+            if t.shape[d] != 1 and t.stride(d) != expect:
+                ok = False
+                break
+            expect *= t.shape[d]
+    if ok and t.shape[-2] != 1 and ld < C:
+        ok = False
+    if not ok:
+        t = t.contiguous()
+        ld = C
+    return t, ld
+
+
+def _nrows(t):
+    return t.numel() // t.shape[-1]
+
+
+def _desc(x_shape, cout, k, stride, ldx, ldy):
+    n, h, w, cin = x_shape
+    pad = k // 2
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    return ConvDesc(n, h, w, cin, ho, wo, cout, k, k, stride, pad, ldx, ldy)
+
+
+def _ohwi(w):
+    """Conv weights are (Cout,Cin,KH,KW) tensors in channels_last memory = OHWI; Linear weights are (N,K)."""
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    return w
+
+
+def _wgrad(dy, lddy, x, ldx, w, d):
+    dw = torch.empty_strided(w.shape, w.stride(), dtype=w.dtype, device=w.device)
+    nbytes = lib.conv_wgrad_workspace(d)
+    ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
+    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
+                   _stream())
+    return dw
+
+
+class _ConvBnAct(Function):
+    """act(BN(conv(x))) [+ residual]; training-mode BN statistics come out of the conv epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum):
+        x, ldx = rows_of(x)
+        w = _ohwi(w)
+        cout, k = w.shape[0], w.shape[2]
+        d = _desc(x.shape, cout, k, stride, ldx, cout)
+        y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+        rows = d.N * d.Ho * d.Wo
+        mi = torch.empty(2 * cout, dtype=x.dtype, device=x.device)
+        s = _stream()
+        if training:
+            nrb = lib.conv_fwd_row_blocks(d)
+            part = scratch(nrb * 2 * cout, x.device)
+            lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), d, s)
+            lib.bn_finalize(part.data_ptr(), nrb, rows, cout, eps, momentum, rmean.data_ptr(), rvar.data_ptr(),
+                            nbt.data_ptr() if nbt is not None else None, mi.data_ptr(), s)
+        else:
+            lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, d, s)
+            lib.bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), cout, eps, mi.data_ptr(), s)
+        out = torch.empty_like(y)
+        if residual is not None:
+            residual, ldr = rows_of(residual)
+        lib.bn_act_fwd(y.data_ptr(), cout, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                       residual.data_ptr() if residual is not None else None, ldr if residual is not None else 0,
+                       out.data_ptr(), cout, rows, cout, act, s)
+        ctx.save_for_backward(x, w, y, mi, gamma, beta)
+        ctx.cfg = (d, act, training, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, y, mi, gamma, beta = ctx.saved_tensors
+        d, act, training, has_res = ctx.cfg
+        dout, ldd = rows_of(dout)
+        cout = d.Cout
+        rows = d.N * d.Ho * d.Wo
+        s = _stream()
+        nparts = lib.bn_bwd_parts(rows)
+        part = scratch(nparts * 2 * cout, x.device)
+        lib.bn_act_bwd_reduce(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                              part.data_ptr(), rows, cout, act, s)
+        dy = torch.empty_like(y)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        lib.bn_act_bwd_apply(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                             part.data_ptr(), nparts, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), rows, cout,
+                             act, 0 if training else 1, s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
+            dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
+            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
+        dw = _wgrad(dy, cout, x, d.ldx, w, d) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None
+
+
+def conv_bn_act(x, w, gamma, beta, rmean, rvar, nbt, stride=1, act=ACT_SILU, residual=None, training=True, eps=1e-3,
+                momentum=0.03):
+    return _ConvBnAct.apply(x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum)
+
+
+class _ConvBias(Function):
+    """conv(x, w) [+ bias] without normalisation: Detect heads, the CEM stencil bank, FFM 1x1 gates, nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride):
+        x, ldx = rows_of(x)
+        w = _ohwi(w)
+        if w.dim() == 2:
+            cout, k = w.shape[0], 1
+            xs = (_nrows(x), 1, 1, x.shape[-1])
+        else:
+            cout, k = w.shape[0], w.shape[2]
+            xs = tuple(x.shape)
+        d = _desc(xs, cout, k, stride, ldx, cout)
+        oshape = (*x.shape[:-1], cout) if w.dim() == 2 else (d.N, d.Ho, d.Wo, cout)
+        y = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        lib.conv_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), None, d,
+                     _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (d, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d, has_bias = ctx.cfg
+        dy, lddy = rows_of(dy)
+        s = _stream()
+        dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, lddy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.ldx, lddy)
+            dw = _wgrad(dy, lddy, x, d.ldx, w, dwd)
+        db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            rows = d.N * d.Ho * d.Wo
+            db = torch.empty(d.Cout, dtype=x.dtype, device=x.device)
+            part = scratch(lib.bn_bwd_parts(rows) * d.Cout, x.device)
+            lib.colsum(dy.data_ptr(), lddy, rows, d.Cout, part.data_ptr(), db.data_ptr(), s)
+        return dx, dw, db, None
+
+
+def conv_bias(x, w, bias=None, stride=1):
+    return _ConvBias.apply(x, w, bias, stride)
+
+
+def linear(x, w, bias=None):
+    return _ConvBias.apply(x, w, bias, 1)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, lda = rows_of(a)
+        b, ldb = rows_of(b)
+        out = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
+        c = a.shape[-1]
+        lib.add(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), c, _nrows(a), c, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Concat(Function):
+    """Channel concat of NHWC tensors; the backward hands out channel-slice views (no copy)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctot = sum(x.shape[-1] for x in xs)
+        out = torch.empty((*xs[0].shape[:-1], ctot), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        s = _stream()
+        for x in xs:
+            x, ld = rows_of(x)
+            c = x.shape[-1]
+            lib.copy2d(x.data_ptr(), ld, out.data_ptr() + 4 * off, ctot, _nrows(x), c, s)
+            off += c
+        ctx.sizes = [x.shape[-1] for x in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.sizes:
+            outs.append(g[..., off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat(xs):
+    return _Concat.apply(*xs)
+
+
+class _Upsample2x(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = rows_of(x)
+        if ld != x.shape[-1]:
+            x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        lib.upsample2x(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        lib.upsample2x_bwd(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _SppPool(Function):
+    """x -> cat(x, mp5, mp9, mp13) along channels (cascaded 5x5 max-pools)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = rows_of(x)
+        n, h, w, c = x.shape
+        out = torch.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
+        lib.spp_pool_fwd(x.data_ptr(), ld, out.data_ptr(), 4 * c, n, h, w, c, _stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        x, ld = rows_of(x)
+        g, ldg = rows_of(g)
+        n, h, w, c = x.shape
+        dx = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        lib.spp_pool_bwd(x.data_ptr(), ld, g.data_ptr(), ldg, dx.data_ptr(), c, n, h, w, c, _stream())
+        return dx
+
+
+def spp_pool(x):
+    return _SppPool.apply(x)
+
+
+def nchw_to_nhwc(x):
+    """Boundary op (no gradient: the model inputs are images).  Accepts strided NCHW views (train.py:744-745)."""
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    sn, sc, sh, sw = x.stride()
+    lib.nchw_to_nhwc(x.data_ptr(), sn, sc, sh, sw, y.data_ptr(), n, c, h, w, _stream())
+    return y
+
+
+class _SpaceToDepth(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // 2, w // 2, 4 * c), dtype=x.dtype, device=x.device)
+        lib.space_to_depth(x.data_ptr(), y.data_ptr(), n, h, w, c, 0, _stream())
+        ctx.shape = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        lib.space_to_depth(g.data_ptr(), dx.data_ptr(), n, h, w, c, 1, _stream())
+        return dx
+
+
+def space_to_depth(x):
+    return _SpaceToDepth.apply(x)
+
+
+class _HeadPermute(Function):
+    """(B,ny,nx,na*no) -> (B,na,ny,nx,no) contiguous, as Detect returns it (yolo_test.py:54-55)."""
+
+    @staticmethod
+    def forward(ctx, x, na):
+        x = x.contiguous()
+        b, ny, nx, c = x.shape
+        no = c // na
+        y = torch.empty((b, na, ny, nx, no), dtype=x.dtype, device=x.device)
+        lib.head_permute(x.data_ptr(), y.data_ptr(), b, na, no, ny * nx, 0, _stream())
+        ctx.cfg = (b, na, no, ny, nx)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        b, na, no, ny, nx = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty((b, ny, nx, na * no), dtype=g.dtype, device=g.device)
+        lib.head_permute(g.data_ptr(), dx.data_ptr(), b, na, no, ny * nx, 1, _stream())
+        return dx, None
+
+
+def head_permute(x, na):
+    return _HeadPermute.apply(x, na)
