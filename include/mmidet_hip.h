@@ -112,6 +112,56 @@ int mmi_spp_pool_fwd(const float* x, int ldx, float* out, int ldo, int N, int H,
 int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int ldd, float* dx, int lddx, int N, int H, int W,
                      int C, void* stream);
 
+/* ---- fusion transformers, token side (models/common.py:1147-1267, 476-503, 529) ---------------------------------- */
+/* out = (a [+ b broadcast with period bmod]) * keep/(1-p); keep = hash(seed, index) >= p*2^32 (p = 0: plain add).
+ * nn.Dropout at common.py:326,1173-1174,1258 and the positional-embedding add at common.py:529,1347.  The same call
+ * with b=NULL applied to the incoming gradient is the backward. */
+int mmi_dropout(const float* a, const float* b, int64_t bmod, float* out, int64_t n, float p, uint64_t seed, void* stream);
+int mmi_gelu_fwd(const float* x, float* y, int64_t n, void* stream);                       /* nn.GELU (erf), common.py:1256 */
+int mmi_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int mmi_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);                    /* common.py:335,477,480 */
+int mmi_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+int mmi_mul(const float* a, const float* b, float* out, int64_t n, void* stream);          /* common.py:502-503 */
+int mmi_scale(const float* a, const float* scalar_dev, float* out, int64_t n, void* stream); /* out = a * scalar_dev[0] */
+/* nn.LayerNorm over the last dim (common.py:1250-1251, 323, 1294); stats[rows][2] = (mean, rstd) */
+int mmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int rows, int C,
+                      float eps, void* stream);
+int mmi_layernorm_bwd_parts(int rows);
+int mmi_layernorm_bwd(const float* x, const float* gamma, const float* stats, const float* dy, float* dx, float* partials,
+                      float* dgamma, float* dbeta, int rows, int C, void* stream); /* partials: parts*2*C floats */
+/* SelfAttention core over T=128 tokens (common.py:1206-1231): q,k,v,out are (B,128,heads*dk) with row stride ld; head h
+ * owns channels [h*dk,(h+1)*dk).  probs (B,heads,128,128) receives the softmax (saved for backward); attention dropout
+ * is regenerated from (seed) in the backward. */
+int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out, float* probs, int B, int heads, int dk,
+                      int ld, float p_drop, uint64_t seed, void* stream);
+int mmi_attention_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout, float* dq,
+                      float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop, uint64_t seed, void* stream);
+
+/* ---- fusion stack, spatial side ------------------------------------------------------------------------------------ */
+/* nn.AdaptiveAvgPool2d((8,8)) (common.py:395-396, 1331-1332) written straight into the token layout:
+ * out[n*out_batch_stride + (oi*8+oj)*out_ld + c]. */
+int mmi_avgpool8_fwd(const float* x, int ldx, int N, int H, int W, int C, float* out, int64_t out_batch_stride, int out_ld,
+                     void* stream);
+int mmi_avgpool8_bwd(const float* dpool, int64_t d_batch_stride, int d_ld, float* dx, int lddx, int N, int H, int W, int C,
+                     void* stream);
+/* out = x + F.interpolate(tok 8x8 -> HxW, bilinear, align_corners=False) (common.py:548-550, 1364-1366 fused with Add2
+ * common.py:924-935); x may be NULL.  tok[n*tok_batch_stride + (i*8+j)*tok_ld + c]. */
+int mmi_upsample_add_fwd(const float* x, int ldx, const float* tok, int64_t tok_batch_stride, int tok_ld, float* out,
+                         int ldo, int N, int H, int W, int C, void* stream);
+int mmi_upsample_add_bwd(const float* dout, int ldd, float* dtok, int64_t tok_batch_stride, int tok_ld, int N, int H, int W,
+                         int C, void* stream);
+/* extract_frequency2 (common.py:37-69) on pooled (B,64,C) token-layout maps + torch.mul(high, pooled) (common.py:440-441):
+ * 8x8 DFT per (b,c) plane, keep the unshifted bins whose bit (u*8+v) is set in keep_mask, inverse, real part -> fp16. */
+int mmi_ffm_highpass(const float* pooled, float* out, int B, int C, uint64_t keep_mask, void* stream);
+/* Seperation_loss (common.py:128-139, 487-494) over four (B,64,8) gate maps -> out[0] */
+int mmi_separation_loss(const float* m_rgb, const float* m_ir, const float* m_rgb_hi, const float* m_ir_hi, int B, float* out,
+                        void* stream);
+/* One pass over the FFM inputs (N,H,W,C): out3 = (SSIMloss, Entropy_loss, ContrastiveValue) of models/yolo_test.py:338-486;
+ * the fused map (mean of the two up-sampled FFM outputs) is recomputed from tokens (N,128,C). */
+size_t mmi_fusion_stats_workspace(void);
+int mmi_fusion_stats(const float* in_rgb, int lda, const float* in_ir, int ldb, const float* tokens, int N, int H, int W,
+                     int C, void* workspace, float* out3, void* stream);
+
 /* ---- detection-loss target assignment (integer kernel, bit-exact) ----------------------------------------------
  * Replaces ComputeLoss.build_targets, utils/loss.py:189-245.  targets: (nt,6) fp32 [img,cls,x,y,w,h]; anchors (nl,na,2)
  * in grid units; grids[nl][2] = (ny,nx) int32 on the DEVICE.  Outputs per level l (capacity cap = 5*na*nt records each):
@@ -120,6 +170,19 @@ int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int ldd, float*
 int mmi_build_targets(const float* targets, int nt, const float* anchors, int nl, int na, const int32_t* grids_dev,
                       float anchor_t, int64_t* idx, int64_t* tcls, float* tbox, float* anch, int32_t* counts,
                       void* stream);
+
+/* ---- detection loss: value and gradient w.r.t. the head outputs in one pass ---------------------------------------
+ * Replaces ComputeLoss.__call__ (utils/loss.py:113-184) + bbox_iou CIoU (utils/general.py:403-447).
+ * preds/dpreds: HOST arrays of nl device pointers to (bs,na,ny,nx,nc+5) tensors; grids_host[nl][2]=(ny,nx) and
+ * balance_host[nl] are host arrays; idx/tcls/tbox/anch/counts/cap are mmi_build_targets outputs (device).  combine:
+ * device vector of ncombine CombineLoss values (may be NULL when ncombine=0).  out5 = (loss*bs, lbox, lobj, lcls,
+ * Detectloss).  dpreds receive d(out5[0])/d(preds). */
+size_t mmi_detect_loss_workspace(int nl, int64_t total_cells, int64_t cap);
+int mmi_detect_loss(const float* const* preds, float* const* dpreds, const int32_t* grids_host, int nl, int bs, int na,
+                    int nc, const int64_t* idx, const int64_t* tcls, const float* tbox, const float* anch,
+                    const int32_t* counts, int64_t cap, const float* balance_host, float hbox, float hobj, float hcls,
+                    float gr, float cp, float cn, const float* combine, int ncombine, float alpha, int flag,
+                    void* workspace, size_t workspace_bytes, float* out5, void* stream);
 
 #ifdef __cplusplus
 }

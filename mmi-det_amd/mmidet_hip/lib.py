@@ -2,7 +2,7 @@
 there is no CPU/ATen fallback for any op of the hot path."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libmmidet_hip.so')
@@ -49,7 +49,31 @@ _SIGS = {
     'mmi_spp_pool_fwd': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_spp_pool_bwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_build_targets': (c_int, [P, c_int, P, c_int, c_int, P, c_float, P, P, P, P, P, P]),
+    'mmi_dropout': (c_int, [P, P, c_int64, P, c_int64, c_float, c_uint64, P]),
+    'mmi_gelu_fwd': (c_int, [P, P, c_int64, P]),
+    'mmi_gelu_bwd': (c_int, [P, P, P, c_int64, P]),
+    'mmi_sigmoid_fwd': (c_int, [P, P, c_int64, P]),
+    'mmi_sigmoid_bwd': (c_int, [P, P, P, c_int64, P]),
+    'mmi_mul': (c_int, [P, P, P, c_int64, P]),
+    'mmi_scale': (c_int, [P, P, P, c_int64, P]),
+    'mmi_layernorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
+    'mmi_layernorm_bwd_parts': (c_int, [c_int]),
+    'mmi_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    'mmi_attention_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),
+    'mmi_attention_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),
+    'mmi_avgpool8_fwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
+    'mmi_avgpool8_bwd': (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample_add_fwd': (c_int, [P, c_int, P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample_add_bwd': (c_int, [P, c_int, P, c_int64, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_ffm_highpass': (c_int, [P, P, c_int, c_int, c_uint64, P]),
+    'mmi_separation_loss': (c_int, [P, P, P, P, c_int, P, P]),
+    'mmi_fusion_stats_workspace': (c_size_t, []),
+    'mmi_fusion_stats': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'mmi_detect_loss_workspace': (c_size_t, [c_int, c_int64, c_int64]),
+    'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
+                                c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
+_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 
@@ -62,7 +86,7 @@ def _bind(name, restype, argtypes):
     fn = getattr(_lib, name)
     fn.restype = restype
     fn.argtypes = argtypes
-    if restype is not c_int or name in ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_bn_bwd_parts'):
+    if restype is not c_int or name in _UNCHECKED:
         return fn
 
     def checked(*args):

@@ -1,0 +1,298 @@
+"""MI355X-native module library for the two-stream MMI-Det graph (drop-in for the reference's models/common.py on the
+training hot path).
+
+Same class names, constructor arguments, attribute names and state_dict keys as the reference
+(/root/reference/models/common.py: Conv 108, Bottleneck 602, C3 637, SPP 681, Focus 696, Concat 740, AdaptiveModule3
+751, EnhanceConv2d 806, Add 914, Add2 924, SelfAttention 1147, myTransformerBlock 1237, GPT 1270, GPT1_fourier 299), but
+every forward runs hand-written HIP kernels through the C ABI (mmidet_hip.ops / fusion_ops) on NHWC activations.
+Parameters live in ordinary nn.Conv2d / nn.BatchNorm2d / nn.Linear / nn.LayerNorm holders (so optimiser grouping by
+isinstance, EMA and checkpoints behave exactly like the reference); the holders' own forward is never called.
+Conv weights are stored channels_last, i.e. physically OHWI, which is the layout the MFMA kernels read.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from mmidet_hip import fusion_ops as F2
+from mmidet_hip import ops
+from mmidet_hip.ops import ACT_LEAKY, ACT_NONE, ACT_SILU
+
+
+def autopad(k, p=None):
+    return k // 2 if p is None else p
+
+
+def _holder_conv(c1, c2, k, s, bias=False):
+    m = nn.Conv2d(c1, c2, k, s, autopad(k), bias=bias)
+    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return m
+
+
+def _bn_args(bn):
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked
+
+
+class Conv(nn.Module):
+    """SiLU(BN(conv(x))) as conv-with-statistics-epilogue + one normalise/activate pass."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        assert g == 1, 'grouped convolutions are outside the two-stream hot path'
+        self.conv = _holder_conv(c1, c2, k, s)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def _act_id(self):
+        if isinstance(self.act, nn.SiLU):
+            return ACT_SILU
+        if isinstance(self.act, nn.LeakyReLU):
+            return ACT_LEAKY
+        assert isinstance(self.act, nn.Identity), 'unsupported activation %r' % self.act
+        return ACT_NONE
+
+    def forward(self, x, residual=None):
+        w, b, rm, rv, nbt = _bn_args(self.bn)
+        return ops.conv_bn_act(x, self.conv.weight, w, b, rm, rv, nbt, stride=self.conv.stride[0], act=self._act_id(),
+                               residual=residual, training=self.bn.training, eps=self.bn.eps,
+                               momentum=self.bn.momentum)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):  # the residual add rides in cv2's normalise/activate pass
+        return self.cv2(self.cv1(x), residual=x if self.add else None)
+
+
+class C3(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def forward(self, x):
+        return self.cv3(ops.concat([self.m(self.cv1(x)), self.cv2(x)]))
+
+
+class SPP(nn.Module):
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        assert tuple(k) == (5, 9, 13), 'the SPP kernel cascades 5x5 pools: k must be (5, 9, 13)'
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+
+    def forward(self, x):
+        return self.cv2(ops.spp_pool(self.cv1(x)))
+
+
+class Focus(nn.Module):
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
+
+    def forward(self, x):
+        return self.conv(ops.space_to_depth(x))
+
+
+class Concat(nn.Module):
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension  # NCHW dim 1 == the contiguous channel axis of the NHWC activations
+
+    def forward(self, x):
+        return ops.concat(list(x))
+
+
+class Add(nn.Module):
+    def __init__(self, arg):
+        super().__init__()
+        self.arg = arg
+
+    def forward(self, x):
+        return ops.add(x[0], x[1])
+
+
+class FusedTokens:
+    """Output of GPT / GPT1_fourier: the two 8x8 token maps whose bilinear up-sampling is fused into Add2."""
+
+    def __init__(self, rgb, ir, hw):
+        self.maps, self.hw = (rgb, ir), hw
+
+    def __getitem__(self, i):  # materialised (B,H,W,C) map, for callers that index the transformer output directly
+        return F2.upsample_only(self.maps[i], *self.hw)
+
+
+class Add2(nn.Module):
+    def __init__(self, c1, index):
+        super().__init__()
+        self.index = index
+
+    def forward(self, x):
+        if isinstance(x[1], FusedTokens):
+            return F2.upsample_add(x[0], x[1].maps[self.index])
+        return ops.add(x[0], x[1][self.index])
+
+
+class EnhanceConv2d(nn.Module):
+    """Fixed edge-stencil bank x trainable per-output factor + bias (parameters as in the reference)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, bias=True,
+                 requires_grad=True):
+        super().__init__()
+        assert kernel_size == 3 and out_channels % 8 == 0 and groups == 1 and stride == 1 and padding == 1
+        bank = ((-1, -2, -1, 0, 0, 0, 1, 2, 1), (-1, 0, 1, -2, 0, 2, -1, 0, 1), (-2, -1, 0, -1, 0, 1, 0, 1, 2),
+                (-2, -1, 0, -1, 0, 1, 0, 1, 2), (0, 1, 0, 1, -4, 1, 0, 1, 0), (0, 1, 0, 1, 4, 1, 0, 1, 0),
+                (-1, -1, -1, 0, 0, 0, 1, 1, 1), (-1, 0, 1, -1, 0, 1, -1, 0, 1))
+        self.bias = nn.Parameter(torch.zeros(out_channels), requires_grad=True) if (bias and requires_grad) else None
+        w = torch.stack([torch.tensor(bank[o % 8], dtype=torch.float32).view(1, 3, 3).expand(in_channels, 3, 3)
+                         for o in range(out_channels)])
+        self.sobel_weight = nn.Parameter(w.contiguous(), requires_grad=False)
+        self.sobel_factor = nn.Parameter(torch.ones(out_channels, 1, 1, 1), requires_grad=requires_grad)
+
+    def forward(self, x):
+        # 5 184-element parameter product; the convolution itself is the HIP implicit GEMM
+        w = (self.sobel_weight * self.sobel_factor).contiguous(memory_format=torch.channels_last)
+        return ops.conv_bias(x, w, self.bias, 1)
+
+
+class AdaptiveModule3(nn.Module):
+    """Contour Enhancement Module."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        c = int(in_channels)
+        self.conv2 = _holder_conv(c, c * 8, 3, 1)
+        self.bn2 = nn.BatchNorm2d(c * 8)
+        self.relu2 = nn.LeakyReLU(0.1)
+        self.sobel = EnhanceConv2d(c * 8, c * 8)
+        self.conv3 = _holder_conv(c * 8, c, 3, 1)
+        self.bn3 = nn.BatchNorm2d(c)
+        self.relu3 = nn.LeakyReLU(0.1)
+
+    def forward(self, x):
+        w, b, rm, rv, nbt = _bn_args(self.bn2)
+        r = ops.conv_bn_act(x, self.conv2.weight, w, b, rm, rv, nbt, 1, ACT_LEAKY, None, self.bn2.training, self.bn2.eps,
+                            self.bn2.momentum)
+        t = ops.add(r, self.sobel(r))
+        w, b, rm, rv, nbt = _bn_args(self.bn3)
+        return ops.conv_bn_act(t, self.conv3.weight, w, b, rm, rv, nbt, 1, ACT_LEAKY, x, self.bn3.training, self.bn3.eps,
+                               self.bn3.momentum)
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, d_model, d_k, d_v, h, attn_pdrop=.1, resid_pdrop=.1):
+        super().__init__()
+        assert d_k % h == 0
+        self.d_model, self.h = d_model, h
+        self.d_k = self.d_v = d_model // h
+        self.que_proj = nn.Linear(d_model, h * self.d_k)
+        self.key_proj = nn.Linear(d_model, h * self.d_k)
+        self.val_proj = nn.Linear(d_model, h * self.d_v)
+        self.out_proj = nn.Linear(h * self.d_v, d_model)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+
+    def forward(self, x):
+        q = ops.linear(x, self.que_proj.weight, self.que_proj.bias)
+        k = ops.linear(x, self.key_proj.weight, self.key_proj.bias)
+        v = ops.linear(x, self.val_proj.weight, self.val_proj.bias)
+        o = F2.attention(q, k, v, self.h, self.attn_drop.p, self.training)
+        o = ops.linear(o, self.out_proj.weight, self.out_proj.bias)
+        return F2.dropout_add(o, None, self.resid_drop.p, self.training)
+
+
+class myTransformerBlock(nn.Module):
+    def __init__(self, d_model, d_k, d_v, h, block_exp, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln_input = nn.LayerNorm(d_model)
+        self.ln_output = nn.LayerNorm(d_model)
+        self.sa = SelfAttention(d_model, d_k, d_v, h, attn_pdrop, resid_pdrop)
+        self.mlp = nn.Sequential(nn.Linear(d_model, block_exp * d_model), nn.GELU(),
+                                 nn.Linear(block_exp * d_model, d_model), nn.Dropout(resid_pdrop))
+
+    def forward(self, x):
+        li, lo = self.ln_input, self.ln_output
+        x = ops.add(x, self.sa(F2.layernorm(x, li.weight, li.bias, li.eps)))
+        hdn = F2.gelu(ops.linear(F2.layernorm(x, lo.weight, lo.bias, lo.eps), self.mlp[0].weight, self.mlp[0].bias))
+        y = ops.linear(hdn, self.mlp[2].weight, self.mlp[2].bias)
+        return ops.add(x, F2.dropout_add(y, None, self.mlp[3].p, self.training))
+
+
+def _init_gpt(module):
+    if isinstance(module, nn.Linear):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+
+
+class GPT(nn.Module):
+    """Cross-modal fusion transformer: pool both streams to 2x8x8 tokens, 8 pre-LN blocks, ln_f, hand the token maps to
+    the Add2 layers (which up-sample and add in one kernel)."""
+
+    def __init__(self, d_model, h=8, block_exp=4, n_layer=8, vert_anchors=8, horz_anchors=8, embd_pdrop=0.1,
+                 attn_pdrop=0.1, resid_pdrop=0.1):
+        super().__init__()
+        assert vert_anchors == 8 and horz_anchors == 8
+        self.n_embd, self.vert_anchors, self.horz_anchors = d_model, vert_anchors, horz_anchors
+        self.pos_emb = nn.Parameter(torch.zeros(1, 2 * vert_anchors * horz_anchors, d_model))
+        self.trans_blocks = nn.Sequential(*[myTransformerBlock(d_model, d_model, d_model, h, block_exp, attn_pdrop,
+                                                               resid_pdrop) for _ in range(n_layer)])
+        self.ln_f = nn.LayerNorm(d_model)
+        self.drop = nn.Dropout(embd_pdrop)
+        self.avgpool = nn.AdaptiveAvgPool2d((vert_anchors, horz_anchors))
+        self.apply(_init_gpt)
+
+    def _transform(self, tok):
+        x = F2.dropout_add(tok, self.pos_emb, self.drop.p, self.training)
+        x = self.trans_blocks(x)
+        return F2.layernorm(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)
+
+    def forward(self, x):
+        rgb, ir = x[0], x[1]
+        assert rgb.shape[0] == ir.shape[0]
+        y = self._transform(F2.pool_tokens(rgb, ir))
+        a, b = F2.split_tokens(y)
+        return FusedTokens(a, b, tuple(rgb.shape[1:3]))
+
+
+class GPT1_fourier(GPT):
+    """Fusion Focus Module: GPT plus the pooled-feature gate (conv1 -> sigmoid -> conv2 -> multiply) and the spectral
+    "pattern" separation loss (no gradient, as in the reference where torch.tensor() detaches it)."""
+
+    def __init__(self, d_model, h=8, block_exp=4, n_layer=8, vert_anchors=8, horz_anchors=8, embd_pdrop=0.1,
+                 attn_pdrop=0.1, resid_pdrop=0.1):
+        super().__init__(d_model, h, block_exp, n_layer, vert_anchors, horz_anchors, embd_pdrop, attn_pdrop, resid_pdrop)
+        self.conv1 = _holder_conv(d_model, 8, 1, 1)
+        self.sig = nn.Sigmoid()
+        self.conv2 = _holder_conv(8, d_model, 1, 1)
+
+    def forward(self, x):
+        rgb, ir = x[0], x[1]
+        assert rgb.shape[0] == ir.shape[0]
+        bs, c = rgb.shape[0], rgb.shape[-1]
+        pooled = F2.pool_tokens(rgb, ir)                                     # (B,128,C): rgb tokens then ir tokens
+        gate = F2.sigmoid(ops.conv_bias(pooled, self.conv1.weight.view(8, c), None, 1))   # (B,128,8)
+        with torch.no_grad():                                                # pattern loss: value only
+            hi = F2.ffm_highpass_mul(pooled.detach().view(bs * 2, 64, c))
+            ghi = F2.sigmoid(ops.conv_bias(hi, self.conv1.weight.detach().view(8, c), None, 1)).view(bs, 2, 64, 8)
+            g = gate.detach().view(bs, 2, 64, 8)
+            self.pattenLoss = F2.separation_loss(g[:, 0], g[:, 1], ghi[:, 0], ghi[:, 1])
+        pt = ops.conv_bias(gate, self.conv2.weight.view(c, 8), None, 1)      # (B,128,C)
+        y = self._transform(F2.mul(pt, pooled))
+        self.last_tokens = y.detach()
+        a, b = F2.split_tokens(y)
+        return FusedTokens(a, b, tuple(rgb.shape[1:3])), self.pattenLoss

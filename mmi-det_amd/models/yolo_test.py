@@ -1,0 +1,207 @@
+"""Two-stream MMI-Det model on the MI355X-native op set: drop-in for the reference's models/yolo_test.py
+(Model 77-273, Detect 29-73, parse_model 548-639) as used by train.py:550,788 / test.py:123 / detect_twostream.py:89.
+
+API kept: Model(cfg, ch=3, nc=None, anchors=None); model(x_rgb, x_ir, augment=False, profile=False) -> (det, Combine_loss);
+model.model[-1] is Detect with .nl .na .nc .no .stride .anchors .anchor_grid .m; layers carry .i .f .type .np;
+model.save/.stride/.names/.yaml; aux attributes ContrastiveValue/SSIMloss/PTLoss/Entropy_loss/Combine_loss; identical
+state_dict keys.  Inputs are NCHW (possibly strided views, train.py:744-745); internally everything is NHWC.
+Reference behaviours deliberately NOT reproduced: per-forward prints (yolo_test.py:253,269 -> device syncs).
+"""
+import logging
+import math
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from mmidet_hip import fusion_ops as F2
+from mmidet_hip import ops
+from models.common import (C3, GPT, SPP, Add, Add2, AdaptiveModule3, Bottleneck, Concat, Conv, Focus, FusedTokens,
+                           GPT1_fourier, _holder_conv)
+from utils.autoanchor import check_anchor_order
+from utils.general import make_divisible
+from utils.torch_utils import initialize_weights, model_info
+
+logger = logging.getLogger(__name__)
+
+
+class Upsample2x(nn.Upsample):
+    """nn.Upsample(None, 2, 'nearest') of the YAML head, on NHWC."""
+
+    def forward(self, x):
+        assert self.mode == 'nearest' and float(self.scale_factor) == 2.0
+        return ops.upsample2x(x)
+
+
+class Detect(nn.Module):
+    stride = None
+    export = False
+
+    def __init__(self, nc=80, anchors=(), ch=()):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.nl, self.na = len(anchors), len(anchors[0]) // 2
+        self.grid = [torch.zeros(1)] * self.nl
+        a = torch.tensor(anchors).float().view(self.nl, -1, 2)
+        self.register_buffer('anchors', a)
+        self.register_buffer('anchor_grid', a.clone().view(self.nl, 1, -1, 1, 1, 2))
+        self.m = nn.ModuleList(_holder_conv(x, self.no * self.na, 1, 1, bias=True) for x in ch)
+
+    def forward(self, x):
+        x = list(x)
+        z = []
+        self.training |= self.export
+        for i in range(self.nl):
+            y = ops.conv_bias(x[i], self.m[i].weight, self.m[i].bias, 1)         # (B,ny,nx,na*no)
+            x[i] = ops.head_permute(y, self.na)                                   # (B,na,ny,nx,no)
+            if not self.training:
+                bs, _, ny, nx, _ = x[i].shape
+                if self.grid[i].shape[2:4] != x[i].shape[2:4] or self.grid[i].device != x[i].device:
+                    self.grid[i] = self._make_grid(nx, ny).to(x[i].device)
+                s = x[i].sigmoid()
+                xy = (s[..., 0:2] * 2. - 0.5 + self.grid[i]) * self.stride[i]
+                wh = (s[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
+                z.append(torch.cat((xy, wh, s[..., 4:]), -1).view(bs, -1, self.no))
+        return x if self.training else (torch.cat(z, 1), x)
+
+    @staticmethod
+    def _make_grid(nx=20, ny=20):
+        yv, xv = torch.meshgrid([torch.arange(ny), torch.arange(nx)], indexing='ij')
+        return torch.stack((xv, yv), 2).view((1, 1, ny, nx, 2)).float()
+
+
+class Model(nn.Module):
+    def __init__(self, cfg='yolov5s.yaml', ch=3, nc=None, anchors=None):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = cfg
+        else:
+            import yaml
+            self.yaml_file = Path(cfg).name
+            with open(cfg) as f:
+                self.yaml = yaml.safe_load(f)
+        self.Enhance = AdaptiveModule3(in_channels=int(ch), out_channels=int(ch))
+        ch = self.yaml['ch'] = self.yaml.get('ch', ch)
+        if nc and nc != self.yaml['nc']:
+            logger.info("Overriding model.yaml nc=%s with nc=%s", self.yaml['nc'], nc)
+            self.yaml['nc'] = nc
+        if anchors:
+            logger.info('Overriding model.yaml anchors with anchors=%s', anchors)
+            self.yaml['anchors'] = round(anchors)
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
+        self.names = [str(i) for i in range(self.yaml['nc'])]
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = torch.tensor([8.0, 16.0, 32.0])            # hard-coded by the reference (yolo_test.py:127)
+            m.anchors /= m.stride.view(-1, 1, 1)
+            check_anchor_order(m)
+            self.stride = m.stride
+            self._initialize_biases()
+        initialize_weights(self)
+        self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = self.Combine_loss = torch.zeros(0)
+
+    def forward(self, x, x2, augment=False, profile=False):
+        if augment:
+            raise NotImplementedError('TTA is dead code in the reference too (yolo_test.py:149 drops x2)')
+        return self.forward_once(x, x2, profile)
+
+    def forward_once(self, x, x2, profile=False):
+        dev = x.device
+        empty = torch.zeros(0, device=dev)
+        self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = empty
+        x = ops.nchw_to_nhwc(x)
+        x2 = ops.nchw_to_nhwc(x2)
+        x = self.Enhance(x)                                        # CEM on the RGB stream only
+        y = []
+        for m in self.model:
+            if m.f != -1 and m.f != -4:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            if m.f == -4:
+                x = m(x2)
+            elif isinstance(m, GPT1_fourier):
+                in_rgb, in_ir = x[0], x[1]
+                x, pt = m(x)
+                with torch.no_grad():                              # CBM + IGM: values only (detached in the reference)
+                    st = F2.fusion_stats(in_rgb, in_ir, m.last_tokens)
+                self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
+            else:
+                x = m(x)
+            y.append(x if m.i in self.save else None)
+        self.Combine_loss = self.SSIMloss                          # yolo_test.py:266-268 (detached SSIM term)
+        return x, self.Combine_loss
+
+    def _initialize_biases(self, cf=None):
+        m = self.model[-1]
+        for mi, s in zip(m.m, m.stride):
+            b = mi.bias.view(m.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / s) ** 2)
+            b.data[:, 5:] += math.log(0.6 / (m.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+
+    def fuse(self):
+        raise NotImplementedError('Conv+BN folding for the inference path is scheduled after the training hot path '
+                                  '(SURVEY.md §8f-3); eval-mode forward uses the running statistics directly')
+
+    def info(self, verbose=False, img_size=640):
+        model_info(self, verbose, img_size)
+
+
+_NAMES = dict(Conv=Conv, Bottleneck=Bottleneck, C3=C3, SPP=SPP, Focus=Focus, Concat=Concat, Add=Add, Add2=Add2, GPT=GPT,
+              GPT1_fourier=GPT1_fourier, Detect=Detect)
+_LITERALS = {'None': None, 'True': True, 'False': False}
+
+
+def parse_model(d, ch):
+    """[from, number, module, args] rows -> nn.Sequential + save list; same grammar and channel/depth rules as the
+    reference, module names resolved through a whitelist instead of eval()."""
+    anchors, nc, gd, gw = d['anchors'], d['nc'], d['depth_multiple'], d['width_multiple']
+    na = (len(anchors[0]) // 2) if isinstance(anchors, list) else anchors
+    no = na * (nc + 5)
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d['backbone'] + d['head']):
+        args = [({'nc': nc, 'anchors': anchors}.get(a, _LITERALS.get(a, a)) if isinstance(a, str) else a) for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n
+        if m == 'nn.Upsample':
+            cls, tname = Upsample2x, 'torch.nn.modules.upsampling.Upsample'
+            c2 = ch[f]
+        else:
+            if m not in _NAMES:
+                raise ValueError('module %r is outside the two-stream hot path' % m)
+            cls = _NAMES[m]
+            tname = 'Detect' if cls is Detect else 'models.common.' + m
+            if cls in (Conv, Bottleneck, SPP, Focus, C3):
+                c1, c2 = (3 if cls is Focus else ch[f]), args[0]
+                if c2 != no:
+                    c2 = make_divisible(c2 * gw, 8)
+                args = [c1, c2, *args[1:]]
+                if cls is C3:
+                    args.insert(2, n)
+                    n = 1
+            elif cls is Concat:
+                c2 = sum(ch[x] for x in f)
+            elif cls is Add:
+                c2 = ch[f[0]]
+                args = [c2]
+            elif cls is Add2:
+                c2 = ch[f[0]]
+                args = [c2, args[1]]
+            elif cls is GPT:
+                c2 = ch[f[0]]
+                args = [c2]
+            elif cls is GPT1_fourier:
+                c2 = args[0]                                        # not width-scaled by the reference (yolo_test.py:607-609)
+                args = [c2]
+            elif cls is Detect:
+                args.append([ch[x] for x in f])
+                if isinstance(args[1], int):
+                    args[1] = [list(range(args[1] * 2))] * len(f)
+        m_ = nn.Sequential(*[cls(*args) for _ in range(n)]) if n > 1 else cls(*args)
+        m_.i, m_.f, m_.type = i, f, tname
+        m_.np = sum(x.numel() for x in m_.parameters())
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)

@@ -1,0 +1,59 @@
+"""Runtime helpers the hot path depends on (reference: utils/torch_utils.py initialize_weights 144-153, is_parallel,
+model_info 204-227, ModelEMA 269-299)."""
+import logging
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+logger = logging.getLogger(__name__)
+
+
+def is_parallel(model):
+    return type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel) or hasattr(model, 'module')
+
+
+def initialize_weights(model):
+    """Parity-critical constants: every BatchNorm2d gets eps=1e-3, momentum=0.03."""
+    for m in model.modules():
+        if type(m) is nn.BatchNorm2d:
+            m.eps = 1e-3
+            m.momentum = 0.03
+        elif type(m) in (nn.Hardswish, nn.LeakyReLU, nn.ReLU, nn.ReLU6):
+            m.inplace = True
+
+
+def model_info(model, verbose=False, img_size=640):
+    n_p = sum(x.numel() for x in model.parameters())
+    n_g = sum(x.numel() for x in model.parameters() if x.requires_grad)
+    logger.info("Model Summary: %d layers, %d parameters, %d gradients", len(list(model.modules())), n_p, n_g)
+
+
+class ModelEMA:
+    """Exponential moving average of every floating state_dict entry, decay ramp 0.9999*(1-exp(-n/2000))."""
+
+    def __init__(self, model, decay=0.9999, updates=0):
+        self.ema = deepcopy(model.module if is_parallel(model) else model).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self._pairs = None
+
+    def update(self, model):
+        with torch.no_grad():
+            self.updates += 1
+            d = self.decay(self.updates)
+            if self._pairs is None:
+                msd = (model.module if is_parallel(model) else model).state_dict()
+                self._pairs = [(v, msd[k]) for k, v in self.ema.state_dict().items() if v.dtype.is_floating_point]
+            ema_t = [a for a, _ in self._pairs]
+            torch._foreach_mul_(ema_t, d)
+            torch._foreach_add_(ema_t, [b.detach() for _, b in self._pairs], alpha=1. - d)
+
+    def update_attr(self, model, include=(), exclude=('process_group', 'reducer')):
+        for k, v in model.__dict__.items():
+            if (len(include) and k not in include) or k.startswith('_') or k in exclude:
+                continue
+            setattr(self.ema, k, v)

@@ -1,0 +1,215 @@
+"""GPU parity: fusion-stack kernels (token side + spatial side + CBM/IGM statistics) against plain torch / the oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_ops_gpu import close, dev, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('rows,C', [(256, 128), (2048, 1024), (130, 32), (64, 2048)])
+def test_layernorm(rows, C):
+    from mmidet_hip import fusion_ops as F2
+    g = torch.Generator().manual_seed(rows + C)
+    x, w, b = torch.randn(rows, C, generator=g) * 2 + 0.3, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    d = dev()
+    xg, wg, bg = (t.to(d).requires_grad_() for t in (x, w, b))
+    yg = F2.layernorm(xg, wg, bg, 1e-5)
+    yg.backward(gy.to(d))
+    close(yg, yr, what='y')
+    close(xg.grad, xr.grad, what='dx')
+    close(wg.grad, wr.grad, what='dgamma')
+    close(bg.grad, br.grad, what='dbeta')
+
+
+def test_pointwise():
+    from mmidet_hip import fusion_ops as F2
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 37, generator=g) * 3
+    y2 = torch.randn(1000, 37, generator=g)
+    d = dev()
+    for name, fn, ref in (('gelu', F2.gelu, F.gelu), ('sigmoid', F2.sigmoid, torch.sigmoid)):
+        xr = x.clone().requires_grad_()
+        r = ref(xr)
+        r.backward(y2)
+        xg = x.to(d).requires_grad_()
+        o = fn(xg)
+        o.backward(y2.to(d))
+        close(o, r, what=name, tol=1e-5)
+        close(xg.grad, xr.grad, what='d' + name, tol=1e-5)
+    ar, br = x.clone().requires_grad_(), y2.clone().requires_grad_()
+    (ar * br).backward(x)
+    ag, bg = x.to(d).requires_grad_(), y2.to(d).requires_grad_()
+    o = F2.mul(ag, bg)
+    o.backward(x.to(d))
+    assert torch.equal(o.cpu(), (x * y2))
+    assert torch.equal(ag.grad.cpu(), ar.grad) and torch.equal(bg.grad.cpu(), br.grad)
+
+
+def test_dropout_add():
+    from mmidet_hip import fusion_ops as F2
+    d = dev()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(4, 128, 64, generator=g)
+    pos = torch.randn(1, 128, 64, generator=g)
+    ag, pg = a.to(d).requires_grad_(), pos.to(d).requires_grad_()
+    o = F2.dropout_add(ag, pg, 0.0, True)                       # p = 0: exact broadcast add
+    assert torch.equal(o.cpu(), a + pos)
+    o.backward(torch.ones_like(o))
+    assert torch.equal(ag.grad.cpu(), torch.ones_like(a))
+    close(pg.grad, torch.full_like(pos, 4.0), what='dpos', tol=1e-6)
+    big = torch.ones(64, 128, 256, device=d, requires_grad=True)
+    o = F2.dropout_add(big, None, 0.1, True)
+    keep = (o != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.005, keep
+    assert torch.allclose(o[o != 0], torch.tensor(1 / 0.9, device=d))
+    o.backward(torch.ones_like(o))
+    assert torch.equal(big.grad, o.detach())                    # the backward regenerates the same mask
+    assert F2.dropout_add(big, None, 0.1, False) is big         # eval: identity
+
+
+@pytest.mark.parametrize('B,C,heads', [(2, 128, 8), (2, 256, 8), (3, 512, 8), (2, 1024, 8), (2, 32, 8)])
+def test_attention(B, C, heads):
+    """softmax(QK^T/sqrt(dk))V per head (models/common.py:1206-1231), forward and backward, no dropout."""
+    from mmidet_hip import fusion_ops as F2
+    g = torch.Generator().manual_seed(B * C)
+    q, k, v = (torch.randn(B, 128, C, generator=g) for _ in range(3))
+    dk = C // heads
+
+    def ref(q, k, v):
+        qh = q.view(B, 128, heads, dk).permute(0, 2, 1, 3)
+        kh = k.view(B, 128, heads, dk).permute(0, 2, 3, 1)
+        vh = v.view(B, 128, heads, dk).permute(0, 2, 1, 3)
+        att = torch.softmax(torch.matmul(qh, kh) / math.sqrt(dk), -1)
+        return torch.matmul(att, vh).permute(0, 2, 1, 3).contiguous().view(B, 128, C)
+    qr, kr, vr = (t.clone().requires_grad_() for t in (q, k, v))
+    o = ref(qr, kr, vr)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    d = dev()
+    qg, kg, vg = (t.to(d).requires_grad_() for t in (q, k, v))
+    og = F2.attention(qg, kg, vg, heads, 0.0, True)
+    og.backward(go.to(d))
+    close(og, o, what='out')
+    close(qg.grad, qr.grad, what='dq')
+    close(kg.grad, kr.grad, what='dk')
+    close(vg.grad, vr.grad, what='dv')
+
+
+def test_attention_dropout_is_consistent():
+    """With attention dropout the backward must use the forward's mask: check against finite differences of the kernel."""
+    from mmidet_hip import fusion_ops as F2
+    from mmidet_hip import lib
+    d = dev()
+    torch.manual_seed(0)
+    B, C, heads = 1, 32, 8
+    q, k, v = (torch.randn(B, 128, C, device=d) for _ in range(3))
+    seed = 1234567
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(qq):
+        out, probs = torch.empty_like(qq), torch.empty(B, heads, 128, 128, device=d)
+        lib.attention_fwd(qq.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, C // heads,
+                          C, 0.3, seed, st)
+        return out, probs
+    out, probs = run(q)
+    w = torch.randn_like(out)
+    dq, dk_, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), w.data_ptr(), dq.data_ptr(), dk_.data_ptr(),
+                      dv.data_ptr(), B, heads, C // heads, C, 0.3, seed, st)
+    dirn = torch.randn_like(q)
+    eps = 1e-2
+    fd = ((run(q + eps * dirn)[0] - run(q - eps * dirn)[0]) * w).sum().item() / (2 * eps)
+    an = (dq * dirn).sum().item()
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
+@pytest.mark.parametrize('hw,C', [((160, 160), 128), ((20, 20), 64), ((40, 24), 32), ((2, 2), 32), ((12, 20), 256)])
+def test_pool_and_upsample_add(hw, C):
+    """AdaptiveAvgPool2d(8) -> tokens and bilinear(8x8 -> HxW) + Add2, forward and backward."""
+    from mmidet_hip import fusion_ops as F2
+    H, W = hw
+    B = 2
+    g = torch.Generator().manual_seed(H * W + C)
+    rgb, ir = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    rr, ii = rgb.clone().requires_grad_(), ir.clone().requires_grad_()
+    tok_r = torch.cat([F.adaptive_avg_pool2d(rr, 8).view(B, C, -1), F.adaptive_avg_pool2d(ii, 8).view(B, C, -1)], 2).permute(0, 2, 1)
+    gt = torch.randn(B, 128, C, generator=g)
+    tok_r.backward(gt)
+    d = dev()
+    rg, ig = nhwc(rgb).to(d).requires_grad_(), nhwc(ir).to(d).requires_grad_()
+    tok = F2.pool_tokens(rg, ig)
+    tok.backward(gt.to(d))
+    close(tok, tok_r, what='tokens', tol=1e-5)
+    close(nchw(rg.grad), rr.grad, what='d rgb', tol=1e-5)
+    close(nchw(ig.grad), ii.grad, what='d ir', tol=1e-5)
+    # upsample + add
+    t = torch.randn(B, 128, C, generator=g)
+    tr, xr = t.clone().requires_grad_(), rgb.clone().requires_grad_()
+    maps = tr.view(B, 2, 8, 8, C).permute(0, 1, 4, 2, 3)
+    outs_r = [xr + F.interpolate(maps[:, i].contiguous(), size=(H, W), mode='bilinear', align_corners=False) for i in range(2)]
+    go = torch.randn(B, C, H, W, generator=g)
+    (outs_r[0] * go + outs_r[1] * (go * 0.5)).sum().backward()
+    tg, xg = t.to(d).requires_grad_(), nhwc(rgb).to(d).requires_grad_()
+    a, b = F2.split_tokens(tg)
+    o0, o1 = F2.upsample_add(xg, a), F2.upsample_add(xg, b)
+    (o0 * nhwc(go).to(d) + o1 * (nhwc(go).to(d) * 0.5)).sum().backward()
+    close(nchw(o0), outs_r[0], what='up0', tol=1e-5)
+    close(nchw(o1), outs_r[1], what='up1', tol=1e-5)
+    close(tg.grad, tr.grad, what='dtok', tol=1e-4)
+    close(nchw(xg.grad), xr.grad, what='dx', tol=1e-5)
+
+
+def test_ffm_spectral_and_separation_loss():
+    """extract_frequency2 high-pass * pooled (common.py:37-69, 440-441) and Seperation_loss (128-139) vs the oracle."""
+    from mmidet_hip import fusion_ops as F2
+    from oracle.ref_model import extract_frequency2, separation_loss
+    g = torch.Generator().manual_seed(4)
+    B, C = 3, 40
+    pooled = torch.randn(B, C, 8, 8, generator=g) * 2
+    _, hi = extract_frequency2(pooled)
+    ref = hi * pooled                                              # fp16 * fp32 -> fp32
+    d = dev()
+    tok = pooled.view(B, C, 64).permute(0, 2, 1).contiguous().to(d)   # (B,64,C)
+    out = F2.ffm_highpass_mul(tok)
+    got = out.cpu().permute(0, 2, 1).reshape(B, C, 8, 8)
+    # fp16 rounding of the high-pass can flip by one fp16 ulp (2^-11 relative) where the two fp32 DFTs differ in the last bit
+    err = (got - ref).abs()
+    assert float((err > 1e-6 + 1.1e-3 * ref.abs()).float().mean()) == 0.0
+    assert float((err > 1e-6 + 1e-5 * ref.abs()).float().mean()) < 0.02
+    gates = [torch.rand(B, 8, 8, 8, generator=g) for _ in range(4)]  # NCHW gate maps (B,8ch,8,8)
+    rows = torch.cat([gates[0].view(-1, 64), gates[1].view(-1, 64), gates[2].view(-1, 64)[:B], gates[3].view(-1, 64)[:B]], 0)
+    ref_l = separation_loss(rows)
+    gg = [t.view(B, 8, 64).permute(0, 2, 1).contiguous().to(d) for t in gates]   # (B,64,8)
+    got_l = F2.separation_loss(*gg)
+    assert abs(float(got_l) - float(ref_l)) < 1e-5 * abs(float(ref_l))
+
+
+@pytest.mark.parametrize('B,H,W,C', [(3, 32, 32, 32), (2, 40, 24, 64), (1, 16, 16, 32)])
+def test_fusion_stats(B, H, W, C):
+    """SSIMloss / Entropy_loss / ContrastiveValue (models/yolo_test.py:338-486) in one pass vs the oracle functions."""
+    from mmidet_hip import fusion_ops as F2
+    from oracle.ref_model import contrastive_value, entropy_loss, fusing_loss2
+    g = torch.Generator().manual_seed(B + H)
+    a = torch.randn(B, C, H, W, generator=g) * 0.5 + 0.3
+    b = torch.randn(B, C, H, W, generator=g) * 0.4 + 0.2
+    tok = torch.randn(B, 128, C, generator=g) * 0.5 + 0.2
+    maps = tok.view(B, 2, 8, 8, C).permute(0, 1, 4, 2, 3)
+    o = [F.interpolate(maps[:, i].contiguous(), size=(H, W), mode='bilinear', align_corners=False) for i in range(2)]
+    avg = torch.mean(torch.stack(o), dim=0)
+    ref = (float(fusing_loss2(a, b, avg, avg)), float(entropy_loss(a, b, avg)), float(contrastive_value(a, b)))
+    d = dev()
+    st = F2.fusion_stats(nhwc(a).to(d), nhwc(b).to(d), tok.to(d)).cpu().tolist()
+    assert abs(st[0] - ref[0]) < 1e-4 * max(1, abs(ref[0])), (st, ref)
+    assert abs(st[1] - ref[1]) < 2e-3 * max(1, abs(ref[1])), (st, ref)     # bin-edge rounding of histc
+    if B > 1:
+        assert abs(st[2] - ref[2]) < 1e-5 * abs(ref[2]), (st, ref)
+    else:
+        assert math.isnan(st[2]) and math.isnan(ref[2])                       # reference quirk at B=1

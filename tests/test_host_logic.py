@@ -1,0 +1,99 @@
+"""CPU: host-side logic of the product package (graph parser, module tree, state_dict compatibility).  Construction
+needs no GPU; running a forward does (there is no fallback), which is asserted too."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import CFG_DIR, GOLDEN, tiny_cfg
+
+
+def test_state_dict_keys_match_reference_fixture():
+    from models.yolo_test import Model
+    for kind in ('fourier', 'add'):
+        g = np.load(os.path.join(GOLDEN, 'model_%s_train.npz' % kind))
+        m = Model(tiny_cfg(kind))
+        assert list(m.state_dict().keys()) == list(g['sd_keys'])
+        assert sum(p.numel() for p in m.parameters()) == int(g['n_params'])
+        shapes_ok = all(tuple(v.shape) == tuple(o.shape) for v, o in zip(m.state_dict().values(), _oracle(kind).state_dict().values()))
+        assert shapes_ok
+
+
+def _oracle(kind):
+    from oracle.ref_model import Model as OModel
+    return OModel(tiny_cfg(kind), dropout=0.0)
+
+
+@pytest.mark.parametrize('kind', ['fourier', 'add'])
+def test_graph_routing_matches_oracle(kind):
+    from models.yolo_test import Model
+    m, o = Model(tiny_cfg(kind)), _oracle(kind)
+    assert m.save == o.save
+    assert len(m.model) == len(o.model)
+    for a, b in zip(m.model, o.model):
+        assert (a.i, a.f, a.type, a.np) == (b.i, b.f, b.type, b.np)
+    det = m.model[-1]
+    assert (det.nl, det.na, det.nc, det.no) == (3, 3, tiny_cfg(kind)['nc'], tiny_cfg(kind)['nc'] + 5)
+    assert torch.equal(det.stride, torch.tensor([8., 16., 32.]))
+    assert torch.allclose(det.anchors, o.model[-1].anchors)
+    assert all(bn.eps == 1e-3 and bn.momentum == 0.03 for bn in m.modules() if isinstance(bn, torch.nn.BatchNorm2d))
+
+
+def test_oracle_state_dict_loads_and_weights_are_ohwi():
+    from models.yolo_test import Model
+    from oracle import portable_init
+    m, o = Model(tiny_cfg('fourier')), _oracle('fourier')
+    sd = portable_init.fill_(o.state_dict())
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    w = m.model[1].conv.weight
+    assert w.shape[2:] == (3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(w, sd['model.1.conv.weight'])
+    # optimiser grouping of train.py:572-579 sees the same module types
+    n_bn = sum(isinstance(v, torch.nn.BatchNorm2d) for v in m.modules())
+    assert n_bn == sum(isinstance(v, torch.nn.BatchNorm2d) for v in o.modules())
+
+
+def test_every_shipped_yaml_parses():
+    from models.yolo_test import Model
+    files = sorted(glob.glob(os.path.join(CFG_DIR, '*.yaml')))
+    assert len(files) == 18
+    for f in files:
+        d = yaml.safe_load(open(f))
+        d['depth_multiple'], gw = 0.33, d['width_multiple']
+        for row in d['backbone']:
+            if row[2] == 'GPT1_fourier':                      # reference quirk B3: the FFM width is not scaled
+                row[3] = [int(128 * gw)]
+        if os.path.basename(f) == 'yolov5l_fusion_transformer_FLIR_aligned.yaml':
+            # the reference file itself carries a typo row `[[14,k], 1, Add, [1]]` (its line 73): unparsable there too
+            with pytest.raises(TypeError):
+                Model(d)
+            continue
+        m = Model(d)
+        assert m.model[-1].nl == 3
+
+
+def test_default_yolov5l_parameter_count():
+    from models.yolo_test import Model
+    m = Model(os.path.join(CFG_DIR, 'yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml'))
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 207.89e6) < 0.01e6, n
+    assert len(m.model) == 50 and len(m.state_dict()) == 1593
+
+
+def test_forward_without_gpu_fails_loudly():
+    from models.yolo_test import Model
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    m = Model(tiny_cfg('add'))
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64))
+
+
+def test_highpass_mask_matches_reference_slicing():
+    from mmidet_hip.fusion_ops import highpass_keep_mask
+    mask = highpass_keep_mask()
+    assert mask == (1 << 64) - 1 - (1 << (3 * 8 + 3))       # everything but unshifted bin (3,3)  

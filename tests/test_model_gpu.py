@@ -1,0 +1,150 @@
+"""GPU parity, path level: the MI355X-native Model + ComputeLoss (through the C ABI) against the oracle on the same
+hash-initialised weights and inputs, and against the fixtures written by the reference itself (tests/golden).
+fp32 tolerance: 1e-3 relative on activations / loss (BASELINE.json north_star); anchor indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, tiny_cfg
+from test_ops_gpu import close, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(kind, size):
+    from models.yolo_test import Model
+    from oracle import portable_init
+    from oracle.ref_loss import scaled_hyp
+    from oracle.ref_model import Model as OModel
+    cfg = tiny_cfg(kind)
+    o = OModel(cfg, dropout=0.0)
+    sd = portable_init.fill_(o.state_dict())
+    o.load_state_dict(sd)
+    m = Model(tiny_cfg(kind))
+    m.load_state_dict(sd, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    for mm in (o, m):
+        mm.nc, mm.gr, mm.hyp = cfg['nc'], 1.0, scaled_hyp(cfg['nc'], size)
+    return m.to(dev()), o, cfg
+
+
+@pytest.mark.parametrize('kind', ['add', 'fourier'])
+def test_train_step_matches_reference_fixture_and_oracle(kind):
+    from oracle import portable_init
+    from oracle.ref_loss import ComputeLoss as OLoss
+    from utils.loss import ComputeLoss
+    g = np.load(os.path.join(GOLDEN, 'model_%s_train.npz' % kind))
+    m, o, cfg = build_pair(kind, 128)
+    imgs, targets = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=1)
+    d = dev()
+    x = imgs.to(d).float() / 255                                   # train.py:743
+    m.train()
+    pred, comb = m(x[:, :3], x[:, 3:])                             # strided NCHW views, as train.py:744-745
+    lf = ComputeLoss(m)
+    loss, items = lf(pred, targets.to(d), comb.reshape(-1))
+    loss.backward()
+    torch.cuda.synchronize()
+    # --- against the reference's own outputs (fixture) ---
+    for i in range(3):
+        close(pred[i], torch.from_numpy(g['pred%d' % i]), what='pred%d vs reference' % i)
+    assert tuple(loss.shape) == tuple(g['loss'].shape)
+    close(loss, torch.from_numpy(g['loss']), what='loss vs reference')
+    close(items, torch.from_numpy(g['items']), what='loss items vs reference')
+    if kind == 'fourier':
+        close(comb, torch.from_numpy(g['combine']), what='Combine_loss', tol=1e-4)
+        close(m.SSIMloss, torch.from_numpy(g['SSIMloss']), what='SSIMloss', tol=1e-4)
+        close(m.PTLoss, torch.from_numpy(g['PTLoss']), what='PTLoss')
+        close(m.Entropy_loss, torch.from_numpy(g['Entropy_loss']), what='Entropy', tol=5e-3)
+        close(m.ContrastiveValue, torch.from_numpy(g['ContrastiveValue']), what='Contrastive', tol=1e-5)
+    else:
+        assert comb.numel() == 0
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert list(grads.keys()) == list(g['grad_names'])
+    mine = torch.tensor([float(v.double().norm()) for v in grads.values()], dtype=torch.float64)
+    ref = torch.from_numpy(g['grad_norms'])
+    bad = ((mine - ref).abs() > 5e-3 * ref + 1e-7).nonzero().flatten().tolist()
+    assert not bad, [(list(grads.keys())[i], float(mine[i]), float(ref[i])) for i in bad[:8]]
+    close(m.Enhance.conv2.weight.grad, torch.from_numpy(g['grad_Enhance_conv2']), what='dW CEM conv2', tol=5e-3)
+    close(m.model[-1].m[0].bias.grad, torch.from_numpy(g['grad_det0_bias']), what='db Detect0', tol=2e-3)
+    tcls, tbox, idx, anch = lf.build_targets(pred, targets.to(d))
+    for i in range(3):                                             # integer path: bit-exact
+        assert np.array_equal(tcls[i].cpu().numpy(), g['tcls%d' % i])
+        assert np.array_equal(torch.stack(idx[i]).cpu().numpy(), g['idx%d' % i])
+        assert np.array_equal(tbox[i].cpu().numpy(), g['tbox%d' % i])
+        assert np.array_equal(anch[i].cpu().numpy(), g['anch%d' % i])
+    sd = m.state_dict()
+    for k in ('Enhance.bn2.running_mean', 'Enhance.bn2.running_var', 'model.1.bn.running_mean', 'model.1.bn.running_var'):
+        close(sd[k], torch.from_numpy(g['after.' + k]), what=k)
+    assert int(sd['model.1.bn.num_batches_tracked']) == 1
+    # --- against the oracle, every parameter gradient elementwise ---
+    o.train()
+    x_cpu = imgs.float() / 255
+    po, co = o(x_cpu[:, :3], x_cpu[:, 3:])
+    lo, _ = OLoss(o)(po, targets, co.reshape(-1))
+    lo.backward()
+    worst = max((rel_err(p.grad, dict(o.named_parameters())[n].grad), n) for n, p in m.named_parameters() if p.grad is not None)
+    assert worst[0] < 2e-2, worst          # deep-net gradient noise in fp32; the norm check above is the tight one
+    med = np.median([rel_err(p.grad, dict(o.named_parameters())[n].grad) for n, p in m.named_parameters() if p.grad is not None])
+    assert med < 1e-3, med
+
+
+@pytest.mark.parametrize('kind', ['add', 'fourier'])
+def test_eval_forward_matches_reference_fixture(kind):
+    from oracle import portable_init
+    g = np.load(os.path.join(GOLDEN, 'model_%s_eval.npz' % kind))
+    m, _, cfg = build_pair(kind, 128)
+    imgs, _ = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=1)
+    x = imgs.to(dev()).float() / 255
+    m.eval()
+    with torch.no_grad():
+        (z, pred), comb = m(x[:, :3], x[:, 3:])
+    close(z, torch.from_numpy(g['z']), what='inference output')
+    for i in range(3):
+        close(pred[i], torch.from_numpy(g['pred%d' % i]), what='pred%d' % i)
+
+
+@pytest.mark.parametrize('bs,per,size,nc', [(4, 8, 256, 6), (16, 32, 640, 6), (2, 0, 128, 9), (1, 1, 64, 1)])
+def test_detect_loss_kernel_vs_oracle(bs, per, size, nc):
+    """ComputeLoss value, items and d loss / d pred on random head outputs (incl. duplicate cells, nt=0, nc=1)."""
+    from oracle import portable_init
+    from oracle.ref_loss import ComputeLoss as OLoss, scaled_hyp
+    from utils.loss import ComputeLoss
+
+    class Det:
+        pass
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+    mo, mg = M(), M().to(dev())
+    a = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).float().view(3, 3, 2)
+    a = a / torch.tensor([8., 16., 32.]).view(3, 1, 1)
+    for mm, dv in ((mo, 'cpu'), (mg, dev())):
+        det = Det()
+        det.nl, det.na, det.nc, det.anchors, det.stride = 3, 3, nc, a.to(dv), torch.tensor([8., 16., 32.])
+        mm.model = [det]
+        mm.hyp, mm.gr = scaled_hyp(nc, size), 1.0
+    _, tg = portable_init.synth_batch(bs, 32, nc, per_image=per, seed=11)
+    g = torch.Generator().manual_seed(bs * per + size)
+    p = [torch.randn(bs, 3, size // s, size // s, nc + 5, generator=g) for s in (8, 16, 32)]
+    comb = torch.tensor([0.37])
+    pr = [t.clone().requires_grad_() for t in p]
+    lo, io = OLoss(mo)(pr, tg, comb)
+    lo.sum().backward()
+    pg = [t.to(dev()).requires_grad_() for t in p]
+    lg, ig = ComputeLoss(mg)(pg, tg.to(dev()), comb.to(dev()))
+    (lg.sum() * 1.0).backward()
+    close(lg, lo, what='loss', tol=1e-5)
+    close(ig, io, what='items', tol=1e-5)
+    for i in range(3):
+        close(pg[i].grad, pr[i].grad, what='dpred%d' % i, tol=1e-4)
+    # empty CombineLoss -> (1,1) shaped loss (reference quirk), Flag=False -> detection loss only
+    l2, _ = ComputeLoss(mg)([t.detach() for t in pg], tg.to(dev()), torch.zeros(0, device=dev()))
+    assert tuple(l2.shape) == (1, 1)
+    l3, i3 = ComputeLoss(mg)([t.detach() for t in pg], tg.to(dev()), comb.to(dev()), Flag=False)
+    close(l3, io[3:4] * bs, what='Flag=False', tol=1e-5)
