@@ -1,0 +1,250 @@
+"""bench.py - paired RGB+IR img/s of one full training step of the two-stream MMI-Det hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload l_fourier|s_add|s_fourier] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = /255 + RGB/IR split -> forward (twin CSPDarknet + CEM/FFM/GPT fusion + PANet + Detect) -> ComputeLoss ->
+backward -> [bucketed RCCL gradient all-reduce on a side stream] -> SGD(nesterov) step -> EMA update, on a synthetic
+uint8 (B,6,640,640) batch already resident in HBM.  Default workload = BASELINE.json configs[2]:
+yolov5l two-stream-fourier, bs=16/GPU, 640x640, nc=6, dropout p=0.1, fp32 MFMA.  Weak scaling: B per GPU is fixed.
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" for the dominant kernel family, the fp32-MFMA implicit
+GEMM, timed live with HIP events on its launch stream + "cpu_baseline": the oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'mmi-det_amd'))
+sys.path.insert(0, REPO)
+
+CFG_DIR = os.path.join(REPO, 'mmi-det_amd', 'models', 'transformer')
+WORKLOADS = {
+    # name: (yaml, depth, width, ffm_channels, nc, default batch, fwd GFLOP per paired image)
+    'l_fourier': ('yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml', 1.0, 1.0, 128, 6, 16, 230.2),
+    's_fourier': ('yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml', 0.33, 0.50, 64, 6, 16, 41.6),
+    's_add': ('yolov5s_fusion_add_vedai.yaml', 0.33, 0.50, None, 9, 8, 32.5),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def load_cfg(name):
+    import yaml
+    fn, gd, gw, ffm, nc, _, _ = WORKLOADS[name]
+    with open(os.path.join(CFG_DIR, fn)) as f:
+        d = yaml.safe_load(f)
+    d['depth_multiple'], d['width_multiple'], d['nc'] = gd, gw, nc
+    if ffm is not None:
+        d['backbone'][6][3] = [ffm]     # the FFM width is not scaled by width_multiple in the reference (quirk B3)
+    return d
+
+
+def synth(bs, size, nc, device, seed):
+    """SURVEY.md §8d synthetic batch: uint8 (B,6,S,S); 8 targets per image."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randint(0, 256, (bs, 6, size, size), dtype=torch.uint8, generator=g)
+    t = 8
+    tg = torch.zeros(bs * t, 6)
+    tg[:, 0] = torch.arange(bs).repeat_interleave(t)
+    tg[:, 1] = torch.randint(0, nc, (bs * t,), generator=g).float()
+    tg[:, 2:4] = 0.1 + 0.8 * torch.rand(bs * t, 2, generator=g)
+    tg[:, 4:6] = 0.02 + 0.30 * torch.rand(bs * t, 2, generator=g)
+    return imgs.to(device), tg.to(device)
+
+
+class ConvTimer:
+    """HIP events around every implicit-GEMM launch (conv fwd / dgrad / wgrad incl. its split-K reduce) on the launch
+    stream.  Events are asynchronous: nothing is serialised, the timed region stays the timed region."""
+
+    def __init__(self):
+        self.recs = []
+        self.on = False
+
+    def install(self):
+        from mmidet_hip import lib
+        timer = self
+
+        def wrap(name, flops_of):
+            fn = getattr(lib, name)
+
+            def timed(*a):
+                if not timer.on:
+                    return fn(*a)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = fn(*a)
+                e.record()
+                timer.recs.append((name, flops_of(a), s, e))
+                return r
+            setattr(lib, name, timed)
+
+        def fl(d):
+            return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW
+        wrap('conv_fwd', lambda a: fl(a[5]))
+        wrap('conv_dgrad', lambda a: fl(a[3]))
+        wrap('conv_wgrad', lambda a: fl(a[5]))
+
+    def summary(self):
+        tot_f = tot_ms = 0.0
+        per = {}
+        for name, f, s, e in self.recs:
+            ms = s.elapsed_time(e)
+            tot_f += f
+            tot_ms += ms
+            p = per.setdefault(name, [0.0, 0.0, 0])
+            p[0] += f
+            p[1] += ms
+            p[2] += 1
+        return tot_f, tot_ms, per
+
+
+def cpu_baseline(workload, seconds_budget=25.0):
+    """The oracle (pure-torch CPU restatement, proven equal to the reference on the golden fixtures) timed on this box's
+    host cores on a bounded sample of the same workload: same graph, same step definition, B=2."""
+    from oracle.ref_loss import ComputeLoss as OLoss, scaled_hyp
+    from oracle.ref_model import Model as OModel
+    cfg = load_cfg(workload)
+    nc = cfg['nc']
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    m = OModel(cfg)
+    m.nc, m.gr, m.hyp = nc, 1.0, scaled_hyp(nc, 640)
+    lf = OLoss(m)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.937, nesterov=True)
+    bs = 2
+    imgs, tg = synth(bs, 640, nc, 'cpu', 1)
+    m.train()
+
+    def one():
+        x = imgs.float() / 255
+        pred, comb = m(x[:, :3], x[:, 3:])
+        loss, _ = lf(pred, tg, comb.reshape(-1))
+        loss.sum().backward()
+        opt.step()
+        opt.zero_grad()
+    one()
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 5:
+            break
+    dt = (time.time() - t0) / n
+    return {'value': round(bs / dt, 4), 'unit': 'paired img/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed steps of the %s graph at B=%d 640x640 (fwd+loss+bwd+SGD, fp32, torch CPU oracle), %.1f s/step'
+                      % (n, workload, bs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='l_fourier', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='paired images per GPU')
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from mmidet_hip.train_step import TrainStep
+    from models.yolo_test import Model
+    torch.manual_seed(2 + rank)                                           # train.py: init_seeds(2 + rank)
+    cfg = load_cfg(args.workload)
+    nc = cfg['nc']
+    bs = args.batch or WORKLOADS[args.workload][5]
+    model = Model(cfg).to(dev)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = args.dropout
+    model.train()
+    ts = TrainStep(model, nc, 640, bs, world_size=world, accumulate=1)
+    if world > 1:
+        from mmidet_hip.ddp import GradReducer
+        red = GradReducer(list(model.parameters()))
+        red.broadcast_parameters(model)
+        ts.reducer = red
+    imgs, tg = synth(bs, 640, nc, dev, 100 + rank)
+
+    timer = ConvTimer()
+    if not args.no_roofline:
+        timer.install()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(imgs, tg)
+    barrier()
+    timer.on = not args.no_roofline
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, items = ts.step(imgs, tg)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    assert torch.isfinite(loss).all(), 'non-finite loss in the timed region'
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * bs * args.steps / dt
+        out = {
+            'metric': 'paired RGB+IR img/s (train step, 640x640 yolov5l two-stream)', 'value': round(value, 3),
+            'unit': 'paired img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': {'l_fourier': 'yolov5l two-stream-fourier (default YAML, CEM+FFM+3xGPT), nc=6',
+                                    's_fourier': 'yolov5s two-stream-fourier (GPT1_fourier[64]), nc=6',
+                                    's_add': 'yolov5s fusion_add (fusion modules off), nc=9'}[args.workload],
+                       'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,640,640)', 'dropout_p': args.dropout,
+                       'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
+                       'loss': [round(float(v), 5) for v in items.tolist()]},
+        }
+        if not args.no_roofline:
+            tot_f, tot_ms, per = timer.summary()
+            ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit GEMM: conv+linear fwd, dgrad, wgrad)',
+                               'launches_per_step': len(timer.recs) // max(args.steps, 1),
+                               'gemm_ms_per_step': round(tot_ms / args.steps, 3),
+                               'per_call': {k: {'TFLOP/s': round(v[0] / (v[1] * 1e-3) / 1e12, 2), 'ms_per_step': round(v[1] / args.steps, 3),
+                                                'launches_per_step': v[2] // args.steps} for k, v in per.items()},
+                               'step_algorithmic_TFLOP/s': round(3 * WORKLOADS[args.workload][6] * 1e9 * value / 1e12, 2)}
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,92 @@
+"""The training step of the hot path: what train.py:743-804 of the reference does per batch, as a reusable harness
+(the reference's full script - logging, W&B, evolve, checkpoint I/O - is out of scope).
+
+    imgs uint8 (B,6,H,W) + targets (nT,6)  ->  /255, split RGB/IR (743-745)  ->  model(rgb, ir) (788)
+    -> ComputeLoss (789)  -> loss *= world_size (790-791)  -> backward (796)  [+ bucketed RCCL all-reduce]
+    -> SGD(nesterov) step, zero_grad (799-803)  -> ModelEMA.update (804)
+
+Optimizer grouping follows train.py:572-589: BN weights (no decay) / other .weight (decay) / .bias; parameters that are
+in no group (pos_emb, sobel_factor, frozen sobel_weight) are never stepped, as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from models.yolo_test import Model  # noqa: F401  (re-export for callers)
+from utils.loss import ComputeLoss
+from utils.torch_utils import ModelEMA
+
+HYP_SCRATCH = dict(lr0=0.01, lrf=0.2, momentum=0.937, weight_decay=0.0005, warmup_epochs=3.0, warmup_momentum=0.8,
+                   warmup_bias_lr=0.1, box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, iou_t=0.20, anchor_t=4.0,
+                   fl_gamma=0.0)  # data/hyp.scratch.yaml:6-22
+
+
+def scale_hyp(hyp, nc, imgsz, nl=3):
+    """train.py:689-691."""
+    h = dict(hyp)
+    h['box'] *= 3. / nl
+    h['cls'] *= nc / 80. * 3. / nl
+    h['obj'] *= (imgsz / 640) ** 2 * 3. / nl
+    return h
+
+
+def param_groups(model):
+    """train.py:572-579."""
+    pg0, pg1, pg2 = [], [], []
+    for _, v in model.named_modules():
+        if hasattr(v, 'bias') and isinstance(v.bias, nn.Parameter):
+            pg2.append(v.bias)
+        if isinstance(v, nn.BatchNorm2d):
+            pg0.append(v.weight)
+        elif hasattr(v, 'weight') and isinstance(v.weight, nn.Parameter):
+            pg1.append(v.weight)
+    return pg0, pg1, pg2
+
+
+def build_optimizer(model, hyp, total_batch_size):
+    nbs = 64
+    accumulate = max(round(nbs / total_batch_size), 1)
+    wd = hyp['weight_decay'] * total_batch_size * accumulate / nbs                      # train.py:568-570
+    pg0, pg1, pg2 = param_groups(model)
+    opt = torch.optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)  # train.py:585-589
+    opt.add_param_group({'params': pg1, 'weight_decay': wd})
+    opt.add_param_group({'params': pg2})
+    return opt, accumulate
+
+
+class TrainStep:
+    def __init__(self, model, nc, imgsz, batch_size, world_size=1, reducer=None, hyp=None, ema=True, accumulate=None):
+        self.model = model
+        self.world_size = world_size
+        self.reducer = reducer
+        hyp = scale_hyp(HYP_SCRATCH if hyp is None else hyp, nc, imgsz)
+        model.nc, model.hyp, model.gr = nc, hyp, 1.0                                    # train.py:693-695
+        self.optimizer, self.accumulate = build_optimizer(model, hyp, batch_size * world_size)
+        if accumulate is not None:                                                      # e.g. 1: optimizer + EMA every batch
+            self.accumulate = accumulate
+        self.ema = ModelEMA(model) if ema else None
+        self.compute_loss = ComputeLoss(model)
+        self.ni = 0
+
+    def step(self, imgs_u8, targets):
+        model = self.model
+        imgs = imgs_u8.float() / 255.0                                                  # train.py:743
+        rgb, ir = imgs[:, :3], imgs[:, 3:]                                              # train.py:744-745 (strided views)
+        pred, comb = model(rgb, ir)                                                     # train.py:788
+        loss, items = self.compute_loss(pred, targets, comb.reshape(-1))                # train.py:789 (+ B2 reshape)
+        if self.world_size > 1:
+            loss = loss * self.world_size                                               # train.py:790-791
+        if self.reducer is not None:
+            self.reducer.prepare()
+        loss.sum().backward()                                                           # train.py:796
+        if self.reducer is not None:
+            self.reducer.finish()                                                       # mean over ranks, as DDP
+        self.ni += 1
+        if self.ni % self.accumulate == 0:                                              # train.py:799-804
+            self.optimizer.step()
+            if self.reducer is not None:
+                self.reducer.zero()                                                     # grads are views of flat buckets
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
+            if self.ema is not None:
+                self.ema.update(model)
+        return loss, items

@@ -86,9 +86,13 @@ def test_train_step_matches_reference_fixture_and_oracle(kind):
     po, co = o(x_cpu[:, :3], x_cpu[:, 3:])
     lo, _ = OLoss(o)(po, targets, co.reshape(-1))
     lo.backward()
-    worst = max((rel_err(p.grad, dict(o.named_parameters())[n].grad), n) for n, p in m.named_parameters() if p.grad is not None)
+    # key_proj.bias has an analytically ZERO gradient (softmax is invariant to a per-query constant), so its computed
+    # value is rounding noise on both sides: excluded from the relative comparison
+    og = dict(o.named_parameters())
+    errs = [(rel_err(p.grad, og[n].grad), n) for n, p in m.named_parameters() if p.grad is not None and 'key_proj.bias' not in n]
+    worst = max(errs)
     assert worst[0] < 2e-2, worst          # deep-net gradient noise in fp32; the norm check above is the tight one
-    med = np.median([rel_err(p.grad, dict(o.named_parameters())[n].grad) for n, p in m.named_parameters() if p.grad is not None])
+    med = np.median([e for e, _ in errs])
     assert med < 1e-3, med
 
 
@@ -134,7 +138,14 @@ def test_detect_loss_kernel_vs_oracle(bs, per, size, nc):
     p = [torch.randn(bs, 3, size // s, size // s, nc + 5, generator=g) for s in (8, 16, 32)]
     comb = torch.tensor([0.37])
     pr = [t.clone().requires_grad_() for t in p]
-    lo, io = OLoss(mo)(pr, tg, comb)
+    # duplicate (b,a,gj,gi) cells: torch's non-accumulating index_put_ (loss.py:135) is UNDEFINED for duplicates and
+    # racy on a threaded CPU; single-threaded it is "last record wins", which is the order the HIP kernel fixes
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        lo, io = OLoss(mo)(pr, tg, comb)
+    finally:
+        torch.set_num_threads(nthreads)
     lo.sum().backward()
     pg = [t.to(dev()).requires_grad_() for t in p]
     lg, ig = ComputeLoss(mg)(pg, tg.to(dev()), comb.to(dev()))
