@@ -103,6 +103,22 @@ class ConvTimer:
         return tot_f, tot_ms, per
 
 
+def host_cores():
+    """CPU share of this process: affinity, capped by the cgroup quota (a 1-GPU box grants 16 cores)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(workload, seconds_budget=25.0):
     """The oracle (pure-torch CPU restatement, proven equal to the reference on the golden fixtures) timed on this box's
     host cores on a bounded sample of the same workload: same graph, same step definition, B=2."""
@@ -110,11 +126,7 @@ def cpu_baseline(workload, seconds_budget=25.0):
     from oracle.ref_model import Model as OModel
     cfg = load_cfg(workload)
     nc = cfg['nc']
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     m = OModel(cfg)
     m.nc, m.gr, m.hyp = nc, 1.0, scaled_hyp(nc, 640)
@@ -132,11 +144,13 @@ def cpu_baseline(workload, seconds_budget=25.0):
         opt.step()
         opt.zero_grad()
     one()
+    print('[bench] cpu_baseline: warm-up step done on %d threads' % cores, file=sys.stderr, flush=True)
     t0 = time.time()
     n = 0
     while True:
         one()
         n += 1
+        print('[bench] cpu_baseline: step %d, %.1f s' % (n, time.time() - t0), file=sys.stderr, flush=True)
         if time.time() - t0 > seconds_budget or n >= 5:
             break
     dt = (time.time() - t0) / n
@@ -157,6 +171,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -197,8 +212,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print('[bench %.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    note('model on device, %d params; warmup' % sum(p.numel() for p in model.parameters()))
+    for i in range(args.warmup):
         ts.step(imgs, tg)
+        torch.cuda.synchronize()
+        note('warmup step %d done, %.1f GB allocated' % (i, torch.cuda.max_memory_allocated() / 2 ** 30))
     barrier()
     timer.on = not args.no_roofline
     t0 = time.perf_counter()

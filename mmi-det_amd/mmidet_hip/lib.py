@@ -2,6 +2,9 @@
 there is no CPU/ATen fallback for any op of the hot path."""
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must come first: torch brings its own libamdhip64; loading ours first puts a second,
+#                              device-less HIP runtime in the process ("no ROCm-capable device is detected")
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')

@@ -89,7 +89,10 @@ def test_train_step_matches_reference_fixture_and_oracle(kind):
     # key_proj.bias has an analytically ZERO gradient (softmax is invariant to a per-query constant), so its computed
     # value is rounding noise on both sides: excluded from the relative comparison
     og = dict(o.named_parameters())
-    errs = [(rel_err(p.grad, og[n].grad), n) for n, p in m.named_parameters() if p.grad is not None and 'key_proj.bias' not in n]
+    # (the same holds for any per-channel constant in front of a 1x1 Conv + train-mode BN, e.g. model.29.ln_f.bias:
+    # BN removes the shift) -> skip parameters whose reference gradient is numerically nil
+    errs = [(rel_err(p.grad, og[n].grad), n) for n, p in m.named_parameters()
+            if p.grad is not None and 'key_proj.bias' not in n and float(og[n].grad.norm()) > 1e-5]
     worst = max(errs)
     assert worst[0] < 2e-2, worst          # deep-net gradient noise in fp32; the norm check above is the tight one
     med = np.median([e for e, _ in errs])
