@@ -61,7 +61,9 @@ int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* workspace, 
  * Replaces nn.BatchNorm2d + nn.SiLU / nn.LeakyReLU at models/common.py:116-122, 766-767, 774-775 and the residual adds
  * at common.py:613, 799.  eps/momentum per utils/torch_utils.py:149-151. */
 /* partials[rb][2][C] -> mean_invstd[2][C]; updates running_mean/var (unbiased var) and increments
- * *num_batches_tracked (int64) when non-NULL. */
+ * *num_batches_tracked (int64) when non-NULL.  The partials buffer must have MMI_BN_FOLD_ROWS spare rows (of 2*C floats)
+ * behind the nparts rows: long lists are folded there first. */
+#define MMI_BN_FOLD_ROWS 64
 int mmi_bn_finalize(const float* partials, int nparts, int64_t rows, int C, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_invstd,
                     void* stream);

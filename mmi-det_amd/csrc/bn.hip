@@ -8,27 +8,54 @@
 
 namespace {
 
-// partials[part][2][C] (fp32) -> mean / invstd, running-stat update.  One block = 64 channels x 4 part-lanes.
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double rows, int C, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   int64_t* __restrict__ nbt, float* __restrict__ mean_invstd) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int p = pl; p < nparts; p += 4) {
+// Sum partial rows [blockIdx.y*chunk, +chunk) of partials[part][2][C] in fp64: one block = 16 channels x 16 part-lanes
+// (64-byte channel segments stay coalesced, a long part list is walked 16-wide).  Result in red[s][0][cl] of warp 0.
+__device__ __forceinline__ void fold_parts(const float* __restrict__ partials, int p0, int p1, int C, int c, int cl, int pl,
+                                           double (*red)[16][16], double& s1, double& s2) {
+  s1 = s2 = 0.0;
+  if (c < C)
+    for (int p = p0 + pl; p < p1; p += 16) {
       s1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
       s2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
     }
-  }
   red[0][pl][cl] = s1;
   red[1][pl][cl] = s2;
   __syncthreads();
+  if (pl == 0) {
+    s1 = s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s1 += red[0][i][cl];
+      s2 += red[1][i][cl];
+    }
+  }
+}
+
+// stage 1 for long part lists: grid (C/16, Y) -> folded[y][2][C]
+__global__ void stat_fold_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ folded, int chunk) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int p0 = blockIdx.y * chunk, p1 = min(p0 + chunk, nparts);
+  double s1, s2;
+  fold_parts(partials, p0, p1, C, c, cl, pl, red, s1, s2);
+  if (pl == 0 && c < C) {
+    folded[((int64_t)blockIdx.y * 2 + 0) * C + c] = (float)s1;
+    folded[((int64_t)blockIdx.y * 2 + 1) * C + c] = (float)s2;
+  }
+}
+
+// partials[part][2][C] (fp32) -> mean / invstd, running-stat update.
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nparts, double rows, int C, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   int64_t* __restrict__ nbt, float* __restrict__ mean_invstd) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1, s2;
+  fold_parts(partials, 0, nparts, C, c, cl, pl, red, s1, s2);
   if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
   if (pl == 0 && c < C) {
-    s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-    s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
     const double mean = s1 / rows;
     double var = s2 / rows - mean * mean;  // biased (normalisation) variance
     if (var < 0.0) var = 0.0;
@@ -147,22 +174,14 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const
 // partials -> dbeta (= sum dz), dgamma (= sum dz*xhat)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int p = pl; p < nparts; p += 4) {
-      s1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
-      s2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
-    }
-  }
-  red[0][pl][cl] = s1;
-  red[1][pl][cl] = s2;
-  __syncthreads();
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1, s2;
+  fold_parts(partials, 0, nparts, C, c, cl, pl, red, s1, s2);
   if (pl == 0 && c < C) {
-    dbeta[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
-    dgamma[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
   }
 }
 
@@ -235,8 +254,17 @@ extern "C" int mmi_bn_finalize(const float* partials, int nparts, int64_t rows, 
                                float* mean_invstd, void* stream) {
   MMI_CHECK_ARG(partials && mean_invstd && nparts > 0 && rows > 0 && C > 0, "mmi_bn_finalize: bad arguments");
   MMI_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mmi_bn_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partials, nparts,
-                     (double)rows, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_invstd);
+  hipStream_t s = (hipStream_t)stream;
+  if (nparts > 1024) {  // long part list (P1/P2-sized maps): fold it 64-wide first, into the slack rows behind the list
+    float* folded = const_cast<float*>(partials) + (int64_t)nparts * 2 * C;
+    const int Y = MMI_BN_FOLD_ROWS, chunk = cdiv(nparts, Y);
+    hipLaunchKernelGGL(stat_fold_kernel, dim3(cdiv(C, 16), Y), dim3(256), 0, s, partials, nparts, C, folded, chunk);
+    MMI_CHECK_LAUNCH("mmi_bn_finalize(fold)");
+    partials = folded;
+    nparts = cdiv(nparts, chunk);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, (double)rows, C, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, mean_invstd);
   MMI_CHECK_LAUNCH("mmi_bn_finalize");
   return MMI_OK;
 }
@@ -296,7 +324,7 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && dy && dgamma && dbeta && rows > 0 && C > 0,
                 "mmi_bn_act_bwd_apply: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
   if (vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta}))
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, y, ldy, dout, ldd,

@@ -28,6 +28,15 @@ struct IgemmP {
   const float* bias;
   float* stat_part;
   int M, Ncol, Kc, KH, KW, P, Q, Hs, Ws, lda, ldc, stride, pad, Ktot, ldb, mtiles, ntiles;
+  int par;  // dgrad of a stride-2 conv: blockIdx.y = output-pixel parity class, which only sees its own taps
+};
+
+// Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
+// Generic conv: all KH x KW taps.  Stride-2 dgrad, pixel parity (pa, qa): rows with p even only meet kh = 1, rows with
+// p odd meet kh in {0, 2} (same for columns), so each class runs 1, 2, 2 or 4 taps instead of 9 (exact FLOPs, no
+// multiply-by-zero work).
+struct Taps {
+  int kh0, khs, kw0, kws, ntw, Ktot;
 };
 
 // one row of the A tile as seen by a loader thread
@@ -60,12 +69,13 @@ __device__ __forceinline__ bool src_pixel(const IgemmP& p, const RowInfo& r, int
 }
 
 template <bool DGRAD, bool VEC>
-__device__ __forceinline__ f32x4 load_a(const IgemmP& p, const RowInfo& r, int k) {
+__device__ __forceinline__ f32x4 load_a(const IgemmP& p, const Taps& tp, const RowInfo& r, int k) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (VEC) {
-    if (k < p.Ktot) {
+    if (k < tp.Ktot) {
       const int tap = k / p.Kc, c = k - tap * p.Kc;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const int ti = tap / tp.ntw, tj = tap - ti * tp.ntw;
+      const int kh = tp.kh0 + tp.khs * ti, kw = tp.kw0 + tp.kws * tj;
       int64_t pix;
       if (src_pixel<DGRAD>(p, r, kh, kw, pix)) v = *reinterpret_cast<const f32x4*>(p.A + pix * p.lda + c);
     }
@@ -73,9 +83,10 @@ __device__ __forceinline__ f32x4 load_a(const IgemmP& p, const RowInfo& r, int k
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ke = k + e;
-      if (ke < p.Ktot) {
+      if (ke < tp.Ktot) {
         const int tap = ke / p.Kc, c = ke - tap * p.Kc;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int ti = tap / tp.ntw, tj = tap - ti * tp.ntw;
+        const int kh = tp.kh0 + tp.khs * ti, kw = tp.kw0 + tp.kws * tj;
         int64_t pix;
         if (src_pixel<DGRAD>(p, r, kh, kw, pix)) v[e] = p.A[pix * p.lda + c];
       }
@@ -103,10 +114,12 @@ __device__ __forceinline__ f32x4 load_b_nk(const IgemmP& p, int n, int k) {
 
 // dgrad weights: B[k=(tap,co)][n=ci] = W[co][tap][ci], n contiguous
 template <bool VEC>
-__device__ __forceinline__ f32x4 load_b_kn(const IgemmP& p, int k, int n) {
+__device__ __forceinline__ f32x4 load_b_kn(const IgemmP& p, const Taps& tp, int k, int n) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (k < p.Ktot) {
-    const int tap = k / p.Kc, co = k - tap * p.Kc;
+  if (k < tp.Ktot) {
+    const int t = k / p.Kc, co = k - t * p.Kc;
+    const int ti = t / tp.ntw, tj = t - ti * tp.ntw;
+    const int tap = (tp.kh0 + tp.khs * ti) * p.KW + tp.kw0 + tp.kws * tj;
     const float* src = p.B + (int64_t)co * p.ldb + (int64_t)tap * p.Ncol + n;
     if (VEC) {
       if (n < p.Ncol) v = *reinterpret_cast<const f32x4*>(src);
@@ -129,10 +142,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   constexpr int RB = BN / 32;                       // fwd: B rows per loader thread
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
   __shared__ __align__(16) float smem[2 * STAGE];
+  __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  Taps tp{0, 1, 0, 1, p.KW, p.Ktot};
+  int pa = 0, qa = 0, Pc = p.P, Qc = p.Q, Mc = p.M, ntile_tot = p.mtiles * p.ntiles;
+  if (DGRAD && p.par) {  // uniform per workgroup
+    pa = blockIdx.y >> 1;
+    qa = blockIdx.y & 1;
+    Pc = (p.P - pa + 1) >> 1;
+    Qc = (p.Q - qa + 1) >> 1;
+    Mc = (p.M / (p.P * p.Q)) * Pc * Qc;
+    tp = Taps{pa ? 0 : 1, pa ? 2 : 0, qa ? 0 : 1, qa ? 2 : 0, qa ? 2 : 1, (pa ? 2 : 1) * (qa ? 2 : 1) * p.Kc};
+    ntile_tot = ((Mc + BM - 1) / BM) * p.ntiles;
+    if ((int)blockIdx.x >= ntile_tot) return;
+  }
+  const int tile = xcd_remap(blockIdx.x, ntile_tot);
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -143,10 +169,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + lrow + 32 * i;
-    if (m < p.M) {
-      const int pq = p.P * p.Q;
+    int orow = -1;
+    if (m < Mc) {
+      const int pq = Pc * Qc;
       const int img = m / pq, rem = m - img * pq;
-      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      int pp = rem / Qc, qq = rem - pp * Qc;
+      if (DGRAD && p.par) {
+        pp = 2 * pp + pa;
+        qq = 2 * qq + qa;
+        orow = (img * p.P + pp) * p.Q + qq;
+      }
       rows[i].base = (int64_t)img * p.Hs * p.Ws;
       rows[i].ph = DGRAD ? pp + p.pad : pp * p.stride - p.pad;
       rows[i].qw = DGRAD ? qq + p.pad : qq * p.stride - p.pad;
@@ -154,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
       rows[i].base = -1;
       rows[i].ph = rows[i].qw = 0;
     }
+    if (DGRAD && p.par && (t & 7) == 0) rowmap[lrow + 32 * i] = orow;  // visible after the K loop's barriers
   }
 
   f32x16 acc[TM][TN];
@@ -169,13 +202,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
 
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = load_a<DGRAD, VEC>(p, rows[i], k0 + kq);
+    for (int i = 0; i < RA; ++i) ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0 + kq);
     if (!DGRAD) {
 #pragma unroll
       for (int i = 0; i < RB; ++i) rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0 + kq);
     } else {
 #pragma unroll
-      for (int i = 0; i < KB_IT; ++i) rb[i] = load_b_kn<VEC>(p, k0 + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+      for (int i = 0; i < KB_IT; ++i) rb[i] = load_b_kn<VEC>(p, tp, k0 + t / VPR + RPI * i, n0 + (t % VPR) * 4);
     }
   };
   auto lstore = [&](int stage) {
@@ -192,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
     }
   };
 
-  const int nk = (p.Ktot + BK - 1) / BK;
+  const int nk = (tp.Ktot + BK - 1) / BK;
   gload(0);
   lstore(0);
   __syncthreads();
@@ -241,11 +274,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int lr = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + lr;
         const float v = acc[i][j][r] + bv;
         s1 += v;
         s2 += v * v;
-        if (cok && row < p.M) p.C[(int64_t)row * p.ldc + col] = v;
+        if (cok && row < Mc) p.C[(int64_t)((DGRAD && p.par) ? rowmap[lr] : row) * p.ldc + col] = v;
       }
     }
     if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
@@ -443,7 +477,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
   IgemmP p = p0;
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
-  const dim3 grid(f.mtiles * f.ntiles), block(256);
+  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_>), grid, block, 0, s, p)
   if (!vec) {
@@ -510,7 +544,10 @@ extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const 
   p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
-  FwdPlan f = plan_tiles(p.M, p.Ncol);
+  p.par = (vec && d->stride == 2 && d->KH == 3) ? 1 : 0;
+  // parity mode: the grid is sized for the largest class (ceil(H/2) x ceil(W/2) pixels per image)
+  const int64_t mrows = p.par ? (int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (int64_t)p.M;
+  FwdPlan f = plan_tiles(mrows, p.Ncol);
   if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(p.Ncol, 64);
   return launch_igemm<true>(p, f, vec, (hipStream_t)stream);
 }
@@ -531,8 +568,8 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   g.mtiles = cdiv(d->Cout, g.bm);
   g.ntiles = cdiv(Ntot, g.bn);
   const int tiles = g.mtiles * g.ntiles;
-  int splits = cdiv(1024, tiles);                                   // ~4 workgroups per CU
-  const int max_splits = (int)((Mpix + 255) / 256);                 // >= 256 pixels (8 K-steps) per split
+  int splits = cdiv(768, tiles);                                    // ~3 workgroups per CU
+  const int max_splits = (int)((Mpix + 511) / 512);                 // >= 512 pixels (16 K-steps) per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;

@@ -93,7 +93,7 @@ class _ConvBnAct(Function):
         s = _stream()
         if training:
             nrb = lib.conv_fwd_row_blocks(d)
-            part = scratch(nrb * 2 * cout, x.device)
+            part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows
             lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), d, s)
             lib.bn_finalize(part.data_ptr(), nrb, rows, cout, eps, momentum, rmean.data_ptr(), rvar.data_ptr(),
                             nbt.data_ptr() if nbt is not None else None, mi.data_ptr(), s)

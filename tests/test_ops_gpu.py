@@ -27,6 +27,9 @@ def rel_err(a, b):
 
 def close(a, b, tol=RTOL, what=''):
     e = rel_err(a, b)
+    if os.environ.get('MMI_ERRLOG'):      # optional: log every measured error (used to rank kernels by accuracy)
+        with open(os.environ['MMI_ERRLOG'], 'a') as f:
+            f.write('%-60s %-28s %.3e (tol %.0e)\n' % (os.environ.get('PYTEST_CURRENT_TEST', '')[:60], what, e, tol))
     assert e < tol, '%s relative L2 error %.3e >= %.1e' % (what, e, tol)
     # elementwise too, scaled by the tensor's magnitude
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
