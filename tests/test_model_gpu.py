@@ -80,23 +80,41 @@ def test_train_step_matches_reference_fixture_and_oracle(kind):
     for k in ('Enhance.bn2.running_mean', 'Enhance.bn2.running_var', 'model.1.bn.running_mean', 'model.1.bn.running_var'):
         close(sd[k], torch.from_numpy(g['after.' + k]), what=k)
     assert int(sd['model.1.bn.num_batches_tracked']) == 1
-    # --- against the oracle, every parameter gradient elementwise ---
+
+
+@pytest.mark.parametrize('kind', ['add', 'fourier'])
+def test_every_parameter_gradient_vs_oracle(kind):
+    """Elementwise gradient parity for every parameter.  Uses batch seed 2: with seed 1 (the fixture batch) one SPP
+    max-pool window of the IR stream holds two values 1 ulp apart, the arg-max flips between any two fp32 evaluation
+    orders and moves ~3e-3 of that stream's gradient (tools/diag_grads.py shows it; fp32-vs-fp64 CPU runs flip too on
+    other seeds).  Norm-level parity on the fixture batch is asserted in the test above."""
+    from oracle import portable_init
+    from oracle.ref_loss import ComputeLoss as OLoss
+    from utils.loss import ComputeLoss
+    m, o, cfg = build_pair(kind, 128)
+    imgs, targets = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=2)
+    d = dev()
+    x = imgs.to(d).float() / 255
+    m.train()
+    pred, comb = m(x[:, :3], x[:, 3:])
+    loss, _ = ComputeLoss(m)(pred, targets.to(d), comb.reshape(-1))
+    loss.backward()
     o.train()
     x_cpu = imgs.float() / 255
     po, co = o(x_cpu[:, :3], x_cpu[:, 3:])
     lo, _ = OLoss(o)(po, targets, co.reshape(-1))
     lo.backward()
-    # key_proj.bias has an analytically ZERO gradient (softmax is invariant to a per-query constant), so its computed
-    # value is rounding noise on both sides: excluded from the relative comparison
+    close(loss, lo, what='loss', tol=1e-4)
+    # key_proj.bias has an analytically ZERO gradient (softmax is invariant to a per-query constant); so has any
+    # per-channel constant in front of a 1x1 Conv + train-mode BN (e.g. model.29.ln_f.bias): skip numerically-nil grads
     og = dict(o.named_parameters())
-    # (the same holds for any per-channel constant in front of a 1x1 Conv + train-mode BN, e.g. model.29.ln_f.bias:
-    # BN removes the shift) -> skip parameters whose reference gradient is numerically nil
     errs = [(rel_err(p.grad, og[n].grad), n) for n, p in m.named_parameters()
             if p.grad is not None and 'key_proj.bias' not in n and float(og[n].grad.norm()) > 1e-5]
+    assert len(errs) > 100
     worst = max(errs)
-    assert worst[0] < 2e-2, worst          # deep-net gradient noise in fp32; the norm check above is the tight one
+    assert worst[0] < 5e-3, worst
     med = np.median([e for e, _ in errs])
-    assert med < 1e-3, med
+    assert med < 5e-4, med
 
 
 @pytest.mark.parametrize('kind', ['add', 'fourier'])
