@@ -21,12 +21,32 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_PAD = BK + 4;  // floats per [row][k] LDS row
 
+// Invalid lanes of the branch-free tile loaders read this instead of being masked afterwards: no select on the loaded
+// value, so hipcc does not have to wait for the load where it is issued (it would: `ok ? v : 0` forces vmcnt(0)).
+// (The pointer travels as a kernel argument so that it stays in the global address space: selecting against the
+// symbol itself degrades every tile load to a flat_load.)
+__device__ f32x4 g_zero4 = {0.f, 0.f, 0.f, 0.f};
+#define ZERO_SRC p.zero
+
+const float* zero_src() {
+  static const float* ptr[64] = {nullptr};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (ptr[dev] == nullptr) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero4)) == hipSuccess) ptr[dev] = (const float*)q;
+  }
+  return ptr[dev];
+}
+
 struct IgemmP {
   const float* A;
   const float* B;
   float* C;
   const float* bias;
   float* stat_part;
+  const float* zero;  // 16 zero bytes in global memory (source of masked lanes)
   int M, Ncol, Kc, KH, KW, P, Q, Hs, Ws, lda, ldc, stride, pad, Ktot, ldb, mtiles, ntiles;
   int par;  // dgrad of a stride-2 conv: blockIdx.y = output-pixel parity class, which only sees its own taps
 };
@@ -37,6 +57,28 @@ struct IgemmP {
 // multiply-by-zero work).
 struct Taps {
   int kh0, khs, kw0, kws, ntw, Ktot;
+};
+
+// Division-free cursor over the K axis: k = tap * Kc + c with tap = ti * ntw + tj; advance() moves k by one slab (BK).
+struct KCur {
+  int c, tap, ti, tj;
+  __device__ __forceinline__ void init(int k, int Kc, int ntw) {
+    tap = k / Kc;
+    c = k - tap * Kc;
+    ti = tap / ntw;
+    tj = tap - ti * ntw;
+  }
+  __device__ __forceinline__ void advance(int Kc, int ntw) {
+    c += BK;
+    while (c >= Kc) {  // at most once when Kc >= BK (every layer but the 12-channel Focus input)
+      c -= Kc;
+      ++tap;
+      if (++tj == ntw) {
+        tj = 0;
+        ++ti;
+      }
+    }
+  }
 };
 
 // one row of the A tile as seen by a loader thread
@@ -198,18 +240,66 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[RA];
-  f32x4 rb[DGRAD ? KB_IT : RB];
+  constexpr int NB = DGRAD ? KB_IT : RB;
+  f32x4 rb[NB];
 
-  auto gload = [&](int k0) {
+  // Vector path: division-free K cursors (advanced by one slab per step) and branch-free loads (an invalid lane reads
+  // the operand's base address and is zeroed by a select), so the loads of the NEXT slab can be issued piecewise
+  // between the MFMA groups of the current one and their address arithmetic runs in the MFMA shadow.
+  const int ntaps = tp.Ktot / p.Kc;
+  KCur ca, cb[NB];
+  int k0cur = 0;
+  if (VEC) {
+    ca.init(kq, p.Kc, tp.ntw);
+    if (DGRAD) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0 + kq);
-    if (!DGRAD) {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0 + kq);
-    } else {
-#pragma unroll
-      for (int i = 0; i < KB_IT; ++i) rb[i] = load_b_kn<VEC>(p, tp, k0 + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+      for (int i = 0; i < NB; ++i) cb[i].init(t / VPR + RPI * i, p.Kc, tp.ntw);
     }
+  }
+  auto load_a_row = [&](int i) {
+    if (!VEC) {
+      ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
+      return;
+    }
+    int64_t pix = 0;
+    const bool ok = (ca.tap < ntaps) & src_pixel<DGRAD>(p, rows[i], tp.kh0 + tp.khs * ca.ti, tp.kw0 + tp.kws * ca.tj, pix);
+    ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
+  };
+  auto load_b_row = [&](int i) {
+    if (!DGRAD) {
+      if (!VEC) {
+        rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0cur + kq);
+        return;
+      }
+      const int n = n0 + lrow + 32 * i, k = k0cur + kq;
+      const bool ok = (n < p.Ncol) & (k < tp.Ktot);
+      rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
+    } else {
+      if (!VEC) {
+        rb[i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+        return;
+      }
+      const int n = n0 + (t % VPR) * 4;
+      const bool ok = (cb[i].tap < ntaps) & (n < p.Ncol);
+      const int tapw = (tp.kh0 + tp.khs * cb[i].ti) * p.KW + tp.kw0 + tp.kws * cb[i].tj;
+      rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)cb[i].c * p.ldb + (int64_t)tapw * p.Ncol + n : ZERO_SRC);
+    }
+  };
+  auto advance = [&]() {  // move every cursor to the next slab
+    k0cur += BK;
+    if (VEC) {
+      ca.advance(p.Kc, tp.ntw);
+      if (DGRAD) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cb[i].advance(p.Kc, tp.ntw);
+      }
+    }
+  };
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) load_a_row(i);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) load_b_row(i);
   };
   auto lstore = [&](int stage) {
     float* As = smem + stage * STAGE;
@@ -226,17 +316,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   };
 
   const int nk = (tp.Ktot + BK - 1) / BK;
-  gload(0);
+  gload();
   lstore(0);
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
   for (int ks = 0; ks < nk; ++ks) {
-    if (ks + 1 < nk) gload((ks + 1) * BK);
+    // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
+    // masked to the zero source, so the last iteration only stages zeros into the idle buffer.
+    advance();
     const float* As = smem + (ks & 1) * STAGE;
     const float* Bs = As + A_ELEMS;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
+      // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
+      // 1024 MFMA cycles then cover the tail of the load latency before the LDS stores below)
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        if (i % 3 == g) load_a_row(i);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if ((RA + i) % 3 == g) load_b_row(i);
       f32x4 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -259,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
-    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
+    lstore((ks + 1) & 1);
     __syncthreads();
   }
 
@@ -309,6 +410,7 @@ struct WgradP {
   const float* DY;
   const float* X;
   float* OUT;  // dw, or slab base when splits > 1
+  const float* zero;
   int Mpix, Cout, Cin, KH, KW, Ho, Wo, H, W, stride, pad, ldx, ldy, Ntot, chunk, mtiles, ntiles, splits;
   int64_t slab_stride;
 };
@@ -356,46 +458,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   f32x4 ra[ITA], rb[ITB];
   const int howo = p.Ho * p.Wo;
 
-  auto gload = [&](int k0) {
+  // division-free pixel cursors for the B (activation) rows: pixel -> (img, oh, ow), advanced by BK per slab
+  int k0cur = kbeg;
+  int cimg[ITB], coh[ITB], cow[ITB];
 #pragma unroll
-    for (int i = 0; i < ITA; ++i) {
-      const int pix = k0 + akr + RPA * i;
+  for (int i = 0; i < ITB; ++i) {
+    const int pix = kbeg + bkr + RPB * i;
+    cimg[i] = pix / howo;
+    const int rem = pix - cimg[i] * howo;
+    coh[i] = rem / p.Wo;
+    cow[i] = rem - coh[i] * p.Wo;
+  }
+  auto advance = [&]() {
+    k0cur += BK;
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) {
+      if (howo == 1) {  // Linear layers: every row is its own 1x1 "image"
+        cimg[i] += BK;
+        continue;
+      }
+      cow[i] += BK;
+      while (cow[i] >= p.Wo) {
+        cow[i] -= p.Wo;
+        if (++coh[i] == p.Ho) {
+          coh[i] = 0;
+          ++cimg[i];
+        }
+      }
+    }
+  };
+  auto load_a_row = [&](int i) {
+    const int pix = k0cur + akr + RPA * i;
+    if (VEC) {  // branch-free: an invalid lane reads the base address and is zeroed
+      const bool ok = (pix < kend) & (am < p.Cout);
+      ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.DY + (int64_t)pix * p.ldy + am : ZERO_SRC);
+    } else {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pix < kend) {
         const float* src = p.DY + (int64_t)pix * p.ldy + am;
-        if (VEC) {
-          if (am < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
-        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (am + e < p.Cout) v[e] = src[e];
-        }
+        for (int e = 0; e < 4; ++e)
+          if (am + e < p.Cout) v[e] = src[e];
       }
       ra[i] = v;
     }
-#pragma unroll
-    for (int i = 0; i < ITB; ++i) {
-      const int pix = k0 + bkr + RPB * i;
+  };
+  auto load_b_row = [&](int i) {
+    const int pix = k0cur + bkr + RPB * i;
+    const int ih0 = coh[i] * p.stride - p.pad, iw0 = cow[i] * p.stride - p.pad;
+    if (VEC) {
+      const int ih = ih0 + b_kh[0], iw = iw0 + b_kw[0];
+      const bool ok = (pix < kend) & b_ok[0] & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
+      rb[i] = *reinterpret_cast<const f32x4*>(
+          ok ? p.X + (((int64_t)cimg[i] * p.H + ih) * p.W + iw) * p.ldx + b_ci[0] : ZERO_SRC);
+    } else {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pix < kend) {
-        const int img = pix / howo, rem = pix - img * howo;
-        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-        if (VEC) {
-          const int ih = ih0 + b_kh[0], iw = iw0 + b_kw[0];
-          if (b_ok[0] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W)
-            v = *reinterpret_cast<const f32x4*>(p.X + (((int64_t)img * p.H + ih) * p.W + iw) * p.ldx + b_ci[0]);
-        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int ih = ih0 + b_kh[e], iw = iw0 + b_kw[e];
-            if (b_ok[e] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W)
-              v[e] = p.X[(((int64_t)img * p.H + ih) * p.W + iw) * p.ldx + b_ci[e]];
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int ih = ih0 + b_kh[e], iw = iw0 + b_kw[e];
+          if (b_ok[e] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W)
+            v[e] = p.X[(((int64_t)cimg[i] * p.H + ih) * p.W + iw) * p.ldx + b_ci[e]];
         }
       }
       rb[i] = v;
     }
+  };
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) load_a_row(i);
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) load_b_row(i);
   };
   auto lstore = [&](int stage) {
     float* As = smem + stage * STAGE;
@@ -409,27 +542,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   const int nk = (kend - kbeg + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
   if (nk > 0) {
-    gload(kbeg);
+    gload();
     lstore(0);
   }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
-    if (ks + 1 < nk) gload(kbeg + (ks + 1) * BK);
+    advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
     const float* As = smem + (ks & 1) * STAGE;
     const float* Bs = As + A_ELEMS;
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
+    for (int g = 0; g < BK / 8; ++g) {  // groups of four k-steps: all fragment reads up front, then 4*TM*TN MFMAs
+      // a third of the next slab's loads ahead of each of the first three groups
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + lh) * BM + wm * WM + i * 32 + l31];
+      for (int i = 0; i < ITA; ++i)
+        if (i % 3 == g) load_a_row(i);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + lh) * BN + wn * WN + j * 32 + l31];
+      for (int i = 0; i < ITB; ++i)
+        if ((ITA + i) % 3 == g) load_b_row(i);
+      float a[4][TM], b[4][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) a[e][i] = As[(2 * (4 * g + e) + lh) * BM + wm * WM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[e][j] = Bs[(2 * (4 * g + e) + lh) * BN + wn * WN + j * 32 + l31];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
     }
-    if (ks + 1 < nk) lstore((ks + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore((ks + 1) & 1);
     __syncthreads();
   }
 
@@ -475,6 +622,11 @@ FwdPlan plan_tiles(int64_t M, int Ncol) {
 template <bool DGRAD>
 int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
   IgemmP p = p0;
+  p.zero = zero_src();
+  if (p.zero == nullptr) {
+    mmi_set_error("igemm: cannot resolve the zero-source symbol");
+    return MMI_ERR_LAUNCH;
+  }
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
@@ -597,6 +749,11 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* 
   }
   WgradP p{};
   p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? (float*)workspace : dw;
+  p.zero = zero_src();
+  if (p.zero == nullptr) {
+    mmi_set_error("mmi_conv_wgrad: cannot resolve the zero-source symbol");
+    return MMI_ERR_LAUNCH;
+  }
   p.Mpix = d->N * d->Ho * d->Wo; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.Ho = d->Ho; p.Wo = d->Wo; p.H = d->H; p.W = d->W; p.stride = d->stride; p.pad = d->pad;
   p.ldx = d->ldx; p.ldy = d->ldy; p.Ntot = d->KH * d->KW * d->Cin; p.chunk = g.chunk;
