@@ -596,12 +596,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   }
 }
 
+// out = sum over splits of slabs[z]: 16-byte lanes, 4 independent loads in flight per thread (HBM-bound)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * n + i];
-  out[i] = s;
+  if (i + 4 <= n && (n & 3) == 0) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      s0 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
+      s1 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)(z + 1) * n + i);
+      s2 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)(z + 2) * n + i);
+      s3 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)(z + 3) * n + i);
+    }
+    for (; z < splits; ++z) s0 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
+    *reinterpret_cast<f32x4*>(out + i) = (s0 + s1) + (s2 + s3);
+  } else {
+    for (int64_t j = i; j < n && j < i + 4; ++j) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * n + j];
+      out[j] = s;
+    }
+  }
 }
 
 struct FwdPlan {
@@ -770,7 +786,7 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* 
 #undef LAUNCHW
   MMI_CHECK_LAUNCH("mmi_conv_wgrad");
   if (g.splits > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 256)), dim3(256), 0, s, (const float*)workspace, dw, wsize, g.splits);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 1024)), dim3(256), 0, s, (const float*)workspace, dw, wsize, g.splits);
     MMI_CHECK_LAUNCH("mmi_conv_wgrad(reduce)");
   }
   return MMI_OK;

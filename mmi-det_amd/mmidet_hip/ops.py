@@ -69,13 +69,40 @@ def _ohwi(w):
     return w
 
 
-def _wgrad(dy, lddy, x, ldx, w, d):
+OVERLAP_WGRAD = True   # run the weight-gradient GEMM on a side HIP stream next to the data-gradient GEMM
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device] = s
+    return s
+
+
+def _wgrad(dy, lddy, x, ldx, w, d, overlap=False):
+    """dw = dy^T x.  With overlap=True the kernel is enqueued on the side stream behind everything already on the
+    current stream; the caller must `_join_side()` before the current stream (or anyone else) touches dw.  dgrad and wgrad
+    of one layer are independent, and two co-running grids fill each other's partial last wave (the fp32-MFMA kernels
+    lose up to a third of the chip to wave quantisation when they run alone)."""
     dw = torch.empty_strided(w.shape, w.stride(), dtype=w.dtype, device=w.device)
     nbytes = lib.conv_wgrad_workspace(d)
-    ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
-    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
-                   _stream())
+    if overlap:
+        main, side = torch.cuda.current_stream(), _side_stream(w.device)
+        ws = scratch(nbytes // 4, w.device, slot=4) if nbytes else None
+        side.wait_stream(main)
+        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
+                       side.cuda_stream)
+    else:
+        ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
+        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
+                       _stream())
     return dw
+
+
+def _join_side(device):
+    torch.cuda.current_stream().wait_stream(_side_stream(device))
 
 
 class _ConvBnAct(Function):
@@ -129,11 +156,14 @@ class _ConvBnAct(Function):
                              part.data_ptr(), nparts, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), rows, cout,
                              act, 0 if training else 1, s)
         dx = None
+        both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
             lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
-        dw = _wgrad(dy, cout, x, d.ldx, w, d) if ctx.needs_input_grad[1] else None
+        if both:
+            _join_side(x.device)
         return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None
 
 
@@ -172,19 +202,22 @@ class _ConvBias(Function):
         s = _stream()
         dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, lddy)
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
-            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
+        both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = None
         if ctx.needs_input_grad[1]:
             dwd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.ldx, lddy)
-            dw = _wgrad(dy, lddy, x, d.ldx, w, dwd)
+            dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
         db = None
         if has_bias and ctx.needs_input_grad[2]:
             rows = d.N * d.Ho * d.Wo
             db = torch.empty(d.Cout, dtype=x.dtype, device=x.device)
             part = scratch(lib.bn_bwd_parts(rows) * d.Cout, x.device)
             lib.colsum(dy.data_ptr(), lddy, rows, d.Cout, part.data_ptr(), db.data_ptr(), s)
+        if both:
+            _join_side(x.device)
         return dx, dw, db, None
 
 

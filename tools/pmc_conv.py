@@ -1,0 +1,28 @@
+"""One conv shape, a handful of launches of fwd / dgrad / wgrad: the target of `rocprofv3 --pmc ...` runs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mmi-det_amd'))
+from mmidet_hip import lib, ops  # noqa: E402
+
+B, H, W, Ci, Co, k, s = [int(v) for v in (sys.argv[1:8] if len(sys.argv) >= 8 else '16 80 80 128 128 3 1'.split())]
+d = torch.device('cuda:0')
+st = torch.cuda.current_stream().cuda_stream
+x = torch.randn(B, H, W, Ci, device=d)
+w = torch.randn(Co, k, k, Ci, device=d) * 0.05
+desc = ops._desc((B, H, W, Ci), Co, k, s, Ci, Co)
+y = torch.empty(B, desc.Ho, desc.Wo, Co, device=d)
+dy = torch.randn_like(y)
+dx = torch.empty_like(x)
+dw = torch.empty_like(w)
+nb = lib.conv_wgrad_workspace(desc)
+ws = torch.empty(max(nb // 4, 1), device=d)
+part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Co, device=d)
+for _ in range(3):
+    lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), desc, st)
+    lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), desc, st)
+    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, desc, st)
+torch.cuda.synchronize()
+print('flop per launch', 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k)
