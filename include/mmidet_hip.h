@@ -118,7 +118,11 @@ int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int ldd, float*
 /* out = (a [+ b broadcast with period bmod]) * keep/(1-p); keep = hash(seed, index) >= p*2^32 (p = 0: plain add).
  * nn.Dropout at common.py:326,1173-1174,1258 and the positional-embedding add at common.py:529,1347.  The same call
  * with b=NULL applied to the incoming gradient is the backward. */
-int mmi_dropout(const float* a, const float* b, int64_t bmod, float* out, int64_t n, float p, uint64_t seed, void* stream);
+int mmi_dropout(const float* a, const float* b, int64_t bmod, float* out, int64_t n, float p, uint64_t seed,
+                const uint64_t* seed_dev, void* stream);
+/* Every dropout mask is hash(seed + (seed_dev ? *seed_dev : 0), element index): `seed` is a per-call-site constant, the
+ * device word is advanced once per training step, so a captured hipGraph draws fresh masks on every replay. */
+int mmi_seed_advance(uint64_t* seed_dev, void* stream);
 int mmi_gelu_fwd(const float* x, float* y, int64_t n, void* stream);                       /* nn.GELU (erf), common.py:1256 */
 int mmi_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 int mmi_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);                    /* common.py:335,477,480 */
@@ -135,9 +139,10 @@ int mmi_layernorm_bwd(const float* x, const float* gamma, const float* stats, co
  * owns channels [h*dk,(h+1)*dk).  probs (B,heads,128,128) receives the softmax (saved for backward); attention dropout
  * is regenerated from (seed) in the backward. */
 int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out, float* probs, int B, int heads, int dk,
-                      int ld, float p_drop, uint64_t seed, void* stream);
+                      int ld, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int mmi_attention_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout, float* dq,
-                      float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop, uint64_t seed, void* stream);
+                      float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop, uint64_t seed,
+                      const uint64_t* seed_dev, void* stream);
 
 /* ---- fusion stack, spatial side ------------------------------------------------------------------------------------ */
 /* nn.AdaptiveAvgPool2d((8,8)) (common.py:395-396, 1331-1332) written straight into the token layout:
@@ -185,6 +190,16 @@ int mmi_detect_loss(const float* const* preds, float* const* dpreds, const int32
                     const int32_t* counts, int64_t cap, const float* balance_host, float hbox, float hobj, float hcls,
                     float gr, float cp, float cn, const float* combine, int ncombine, float alpha, int flag,
                     void* workspace, size_t workspace_bytes, float* out5, void* stream);
+
+/* ---- fused multi-tensor SGD(nesterov) + ModelEMA -------------------------------------------------
+ * Replaces optimizer.step() + ema.update() of train.py:799-804 (torch.optim.SGD nesterov over the 3 groups of
+ * train.py:572-589; utils/torch_utils.py:269-299).  recs_dev: array of 48-byte records
+ * {float* p; const float* g; float* buf; float* ema; int64 n; int32 group; int32 flags(1=SGD,2=EMA,4=16B-aligned)};
+ * chunks_dev: array of {int32 rec; int32 chunk} covering every tensor in MMI_OPT_CHUNK-element pieces;
+ * hyper_dev: 9 floats = lr[3], weight_decay[3], momentum, ema_decay, first_step_flag (all read on the device, so the
+ * launch can live in a captured graph while the schedule changes). */
+#define MMI_OPT_CHUNK 65536
+int mmi_sgd_ema_step(const void* recs_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, void* stream);
 
 #ifdef __cplusplus
 }

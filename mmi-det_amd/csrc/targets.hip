@@ -60,7 +60,7 @@ __global__ __launch_bounds__(TB) void build_targets_kernel(const float* __restri
       ah = anc_l[2 * a + 1];
       const float rw = tw / aw, rh = th / ah;                                     // :212
       const float m = fmaxf(fmaxf(rw, 1.0f / rw), fmaxf(rh, 1.0f / rh));          // :213
-      keep = m < anchor_t;
+      keep = (m < anchor_t) && (fimg >= 0.f);  // rows with a negative image index are padding (fixed-shape graph mode)
       if (keep && o > 0) {
         const float gx = (o == 1 || o == 2) ? tx : fnx - tx;  // j,k test gxy; l,m test gxi = gain - gxy   :219-221
         const float gy = (o == 1 || o == 2) ? ty : fny - ty;

@@ -32,7 +32,9 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_
 
 // out = (a [+ b]) * dropmask  (b optional, broadcast over leading dim with period bmod: positional embedding)
 __global__ void dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t bmod,
-                               float* __restrict__ out, int64_t n, uint64_t seed, uint32_t thresh, float inv_keep) {
+                               float* __restrict__ out, int64_t n, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                               uint32_t thresh, float inv_keep) {
+  if (seed_dev != nullptr) seed += seed_dev[0];  // per-step device seed + per-call salt (graph replays stay random)
   GRID_STRIDE(e, n) {
     float v = a[e];
     if (b != nullptr) v += b[e % bmod];
@@ -218,8 +220,10 @@ template <int DK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ out,
                                                        float* __restrict__ probs, int ld, int heads, float scale,
-                                                       uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                       uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                       uint32_t thresh, float inv_keep) {
   __shared__ __align__(16) float sm[T * DK + T * PS];
+  if (seed_dev != nullptr) seed += seed_dev[0];
   float* KV = sm;            // [T][DK]
   float* P = sm + T * DK;    // [T][PS]
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
@@ -295,8 +299,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ v, const float* __restrict__ probs,
                                                        const float* __restrict__ dout, float* __restrict__ dq,
                                                        float* __restrict__ dk, float* __restrict__ dv, int ld, int heads,
-                                                       float scale, uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                       float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                       uint32_t thresh, float inv_keep) {
   __shared__ __align__(16) float sm[T * DK + T * PS];
+  if (seed_dev != nullptr) seed += seed_dev[0];
   float* OP = sm;           // [T][DK] operand buffer
   float* S = sm + T * DK;   // [T][PS]
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
@@ -397,6 +403,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+__global__ void seed_advance_kernel(uint64_t* seed) {
+  uint64_t z = seed[0] + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  seed[0] = z ^ (z >> 31);
+}
+
 inline uint32_t drop_thresh(float p) {
   if (p <= 0.f) return 0u;
   const double t = (double)p * 4294967296.0;
@@ -419,10 +432,10 @@ int attn_dispatch(int dk, F&& f) {
 }  // namespace
 
 extern "C" int mmi_dropout(const float* a, const float* b, int64_t bmod, float* out, int64_t n, float p, uint64_t seed,
-                           void* stream) {
+                           const uint64_t* seed_dev, void* stream) {
   MMI_CHECK_ARG(a && out && n > 0 && p >= 0.f && p < 1.f && (!b || bmod > 0), "mmi_dropout: bad arguments");
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, bmod, out, n, seed,
-                     drop_thresh(p), 1.0f / (1.0f - p));
+                     seed_dev, drop_thresh(p), 1.0f / (1.0f - p));
   MMI_CHECK_LAUNCH("mmi_dropout");
   return MMI_OK;
 }
@@ -486,7 +499,8 @@ extern "C" int mmi_layernorm_bwd(const float* x, const float* gamma, const float
 }
 
 extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out, float* probs, int B,
-                                 int heads, int dk, int ld, float p_drop, uint64_t seed, void* stream) {
+                                 int heads, int dk, int ld, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                                 void* stream) {
   MMI_CHECK_ARG(q && k && v && out && probs && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0, "mmi_attention_fwd: bad arguments");
   const float scale = 1.0f / sqrtf((float)dk);
   const uint32_t th = drop_thresh(p_drop);
@@ -494,7 +508,7 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
   hipStream_t s = (hipStream_t)stream;
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
-    hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, th, ik);
+    hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
     return 0;
   });
   MMI_CHECK_ARG(rc == 0, "mmi_attention_fwd: head dim %d unsupported (4,8,16,32,64,128)", dk);
@@ -504,7 +518,7 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
 
 extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                                  float* dq, float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop,
-                                 uint64_t seed, void* stream) {
+                                 uint64_t seed, const uint64_t* seed_dev, void* stream) {
   MMI_CHECK_ARG(q && k && v && probs && dout && dq && dk_ && dv && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0,
                 "mmi_attention_bwd: bad arguments");
   const float scale = 1.0f / sqrtf((float)dk);
@@ -514,10 +528,17 @@ extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v,
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
     hipLaunchKernelGGL(attn_bwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads, scale,
-                       seed, th, ik);
+                       seed, seed_dev, th, ik);
     return 0;
   });
   MMI_CHECK_ARG(rc == 0, "mmi_attention_bwd: head dim %d unsupported (4,8,16,32,64,128)", dk);
   MMI_CHECK_LAUNCH("mmi_attention_bwd");
+  return MMI_OK;
+}
+
+extern "C" int mmi_seed_advance(uint64_t* seed_dev, void* stream) {
+  MMI_CHECK_ARG(seed_dev != nullptr, "mmi_seed_advance: null pointer");
+  hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed_dev);
+  MMI_CHECK_LAUNCH("mmi_seed_advance");
   return MMI_OK;
 }

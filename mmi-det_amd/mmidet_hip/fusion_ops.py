@@ -7,13 +7,30 @@ from . import lib
 from .ops import _nrows, _stream, rows_of, scratch
 
 _drop_counter = [0]
+_seed_state = {}
 
 
 def next_seed():
-    """Counter-based dropout seeds: reproducible from torch.manual_seed, distinct per call (and per rank when ranks
-    seed differently, as train.py:init_seeds(2 + rank) does)."""
+    """Per-call-site salt of a dropout mask: reproducible from torch.manual_seed, distinct per call (and per rank when
+    ranks seed differently, as train.py:init_seeds(2 + rank) does).  The per-step randomness comes from the device seed
+    word (seed_state), so the salts may be constants baked into a captured graph."""
     _drop_counter[0] += 1
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _drop_counter[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def seed_state(device):
+    """The device-resident 64-bit seed word every dropout kernel adds to its salt."""
+    t = _seed_state.get(device)
+    if t is None:
+        t = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+        _seed_state[device] = t
+    return t
+
+
+def advance_seed(device):
+    """Call once per training step (TrainStep does): new masks for every dropout site, also under graph replay."""
+    lib.seed_advance(seed_state(device).data_ptr(), _stream())
+    _drop_counter[0] = 0
 
 
 class _LayerNorm(Function):
@@ -128,7 +145,7 @@ class _DropoutAdd(Function):
             bmod = b.numel()
             assert a.numel() % bmod == 0
         lib.dropout(a.data_ptr(), b.data_ptr() if b is not None else None, bmod, out.data_ptr(), a.numel(), p, seed,
-                    _stream())
+                    seed_state(a.device).data_ptr() if p > 0 else None, _stream())
         ctx.cfg = (p, seed, bmod, tuple(b.shape) if b is not None else None)
         return out
 
@@ -138,7 +155,8 @@ class _DropoutAdd(Function):
         g = g.contiguous()
         if p > 0:
             da = torch.empty_like(g)
-            lib.dropout(g.data_ptr(), None, 0, da.data_ptr(), g.numel(), p, seed, _stream())
+            lib.dropout(g.data_ptr(), None, 0, da.data_ptr(), g.numel(), p, seed, seed_state(g.device).data_ptr(),
+                        _stream())
         else:
             da = g
         db = None
@@ -167,7 +185,7 @@ class _Attention(Function):
         out = torch.empty_like(q)
         probs = torch.empty((b, heads, t, t), dtype=q.dtype, device=q.device)
         lib.attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), b, heads, dk, c, p,
-                          seed, _stream())
+                          seed, seed_state(q.device).data_ptr() if p > 0 else None, _stream())
         ctx.save_for_backward(q, k, v, probs)
         ctx.cfg = (heads, p, seed)
         return out
@@ -180,7 +198,8 @@ class _Attention(Function):
         b, t, c = q.shape
         dq, dk_, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
-                          dk_.data_ptr(), dv.data_ptr(), b, heads, c // heads, c, p, seed, _stream())
+                          dk_.data_ptr(), dv.data_ptr(), b, heads, c // heads, c, p, seed,
+                          seed_state(q.device).data_ptr() if p > 0 else None, _stream())
         return dq, dk_, dv, None, None, None
 
 

@@ -52,7 +52,8 @@ _SIGS = {
     'mmi_spp_pool_fwd': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_spp_pool_bwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_build_targets': (c_int, [P, c_int, P, c_int, c_int, P, c_float, P, P, P, P, P, P]),
-    'mmi_dropout': (c_int, [P, P, c_int64, P, c_int64, c_float, c_uint64, P]),
+    'mmi_dropout': (c_int, [P, P, c_int64, P, c_int64, c_float, c_uint64, P, P]),
+    'mmi_seed_advance': (c_int, [P, P]),
     'mmi_gelu_fwd': (c_int, [P, P, c_int64, P]),
     'mmi_gelu_bwd': (c_int, [P, P, P, c_int64, P]),
     'mmi_sigmoid_fwd': (c_int, [P, P, c_int64, P]),
@@ -62,8 +63,8 @@ _SIGS = {
     'mmi_layernorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     'mmi_layernorm_bwd_parts': (c_int, [c_int]),
     'mmi_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
-    'mmi_attention_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),
-    'mmi_attention_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P]),
+    'mmi_attention_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
+    'mmi_attention_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
     'mmi_avgpool8_fwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
     'mmi_avgpool8_bwd': (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample_add_fwd': (c_int, [P, c_int, P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -72,6 +73,7 @@ _SIGS = {
     'mmi_separation_loss': (c_int, [P, P, P, P, c_int, P, P]),
     'mmi_fusion_stats_workspace': (c_size_t, []),
     'mmi_fusion_stats': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'mmi_sgd_ema_step': (c_int, [P, P, c_int, P, P]),
     'mmi_detect_loss_workspace': (c_size_t, [c_int, c_int64, c_int64]),
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),

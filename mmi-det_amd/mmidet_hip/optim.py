@@ -1,0 +1,130 @@
+"""Fused SGD(nesterov)+EMA step over the C ABI (csrc/optim.hip): one HIP launch for every parameter/buffer tensor.
+
+Semantics = torch.optim.SGD(nesterov=True, dampening=0) over the reference's three parameter groups (train.py:572-589)
+followed by ModelEMA.update (utils/torch_utils.py:286-299).  `param_groups` is exposed like a torch optimizer's so the
+reference's warm-up / scheduler code (train.py:765-773: `x['lr'] = ...`, `x['momentum'] = ...`) keeps working; the values
+are copied to a 9-float device block right before the launch, which is what lets the launch be replayed from a hipGraph.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+from .ops import _stream
+
+_REC = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('ema', '<u8'), ('n', '<i8'), ('group', '<i4'), ('flags', '<i4')])
+_CHUNK = 65536  # MMI_OPT_CHUNK
+
+
+class FusedSGDEMA:
+    def __init__(self, model, groups, ema_model=None, ema_decay=0.9999, ema_updates=0):
+        """groups: list of dicts {'params': [...], 'lr':, 'momentum':, 'weight_decay':} (at most 3)."""
+        assert 1 <= len(groups) <= 3
+        self.param_groups = groups
+        for g in groups:
+            g.setdefault('initial_lr', g['lr'])
+            g.setdefault('weight_decay', 0.0)
+            g.setdefault('nesterov', True)
+        self.model, self.ema_model = model, ema_model
+        self.ema_decay, self.updates = ema_decay, ema_updates
+        self.device = next(model.parameters()).device
+        self.state = {}        # param -> momentum buffer (same memory layout as the parameter)
+        self._steps = 0
+        self._gptrs = None
+        self._recs_host = self._recs_dev = self._chunks_dev = None
+        self._hyper_host = torch.zeros(9, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(9)
+        self._hyper_dev = torch.zeros(9, dtype=torch.float32, device=self.device)
+        self._build()
+
+    # ---- table construction ------------------------------------------------------------------------------------------
+    def _build(self):
+        msd = self.model.state_dict(keep_vars=True)
+        esd = self.ema_model.state_dict(keep_vars=True) if self.ema_model is not None else {}
+        ema_of = {}
+        for k, v in msd.items():
+            if k in esd and v.dtype.is_floating_point:
+                e = esd[k]
+                assert e.shape == v.shape and e.stride() == v.stride(), 'EMA copy must share the parameter layout: ' + k
+                ema_of[v.data_ptr()] = e
+        rows, self._sgd_params = [], []
+        done = set()
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                if not p.requires_grad:
+                    continue
+                buf = torch.zeros_like(p, memory_format=torch.preserve_format)
+                self.state[p] = buf
+                e = ema_of.get(p.data_ptr())
+                rows.append([p.data_ptr(), 0, buf.data_ptr(), e.data_ptr() if e is not None else 0, p.numel(), gi,
+                             1 | (2 if e is not None else 0)])
+                self._sgd_params.append(p)
+                done.add(p.data_ptr())
+        for k, v in msd.items():            # EMA-only entries: buffers and parameters that are in no group
+            if v.dtype.is_floating_point and v.data_ptr() not in done and v.data_ptr() in ema_of:
+                rows.append([v.data_ptr(), 0, 0, ema_of[v.data_ptr()].data_ptr(), v.numel(), 0, 2])
+                done.add(v.data_ptr())
+        rec = np.zeros(len(rows), dtype=_REC)
+        for i, r in enumerate(rows):
+            rec[i] = tuple(r)
+        self._recs_host = rec
+        chunks = [(i, c) for i, r in enumerate(rows) for c in range((r[4] + _CHUNK - 1) // _CHUNK)]
+        ck = np.array(chunks, dtype=np.int32).reshape(-1, 2)
+        self._nchunks = len(chunks)
+        self._chunks_dev = torch.from_numpy(ck).to(self.device)
+        self._recs_pinned = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).pin_memory() \
+            if torch.cuda.is_available() else torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+        self._recs_dev = torch.empty(self._recs_pinned.numel(), dtype=torch.uint8, device=self.device)
+
+    def _refresh_grads(self):
+        """Gradients are fresh tensors every eager step (AccumulateGrad steals them); re-point the table when they move.
+        Under graph capture/replay the addresses are static and this is a no-op after the capture pass."""
+        ptrs = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self._sgd_params)
+        if ptrs == self._gptrs:
+            return
+        self._gptrs = ptrs
+        rec = self._recs_host
+        n = len(ptrs)
+        aligned = 0
+        for i, (p, gp) in enumerate(zip(self._sgd_params, ptrs)):
+            if gp == 0:
+                raise RuntimeError('parameter without gradient in an optimiser group (all are trained in the reference)')
+            assert p.grad.stride() == p.stride(), 'gradient layout differs from the parameter layout'
+        rec['g'][:n] = np.array(ptrs, dtype=np.uint64)
+        al = ((rec['p'] | rec['g'] | rec['buf'] | rec['ema']) & np.uint64(15)) == 0
+        rec['flags'] = (rec['flags'] & ~np.int32(4)) | np.where(al, 4, 0).astype(np.int32)
+        self._recs_pinned.copy_(torch.from_numpy(rec.view(np.uint8).reshape(-1)))
+        self._recs_dev.copy_(self._recs_pinned, non_blocking=True)
+
+    # ---- per step ----------------------------------------------------------------------------------------------------
+    def upload_hyper(self, advance=True):
+        """Host -> device copy of the 9 hyper-parameters; call before a graph replay (step() calls it itself)."""
+        if advance:
+            self.updates += 1
+        d = self.ema_decay * (1 - math.exp(-self.updates / 2000)) if self.ema_model is not None else 0.0
+        h = self._hyper_host
+        for i in range(3):
+            g = self.param_groups[min(i, len(self.param_groups) - 1)]
+            h[i], h[3 + i] = g['lr'], g['weight_decay']
+        h[6], h[7], h[8] = self.param_groups[0]['momentum'], d, 1.0 if self._steps == 0 else 0.0
+        self._hyper_dev.copy_(h, non_blocking=True)
+        self._steps += 1
+
+    def launch(self):
+        self._refresh_grads()
+        lib.sgd_ema_step(self._recs_dev.data_ptr(), self._chunks_dev.data_ptr(), self._nchunks, self._hyper_dev.data_ptr(),
+                         _stream())
+
+    def step(self):
+        self.upload_hyper()
+        self.launch()
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._sgd_params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+        for p in self.model.parameters():   # parameters in no group (pos_emb, sobel_factor) still receive gradients
+            if p.grad is not None and set_to_none:
+                p.grad = None

@@ -7,6 +7,12 @@
 
 Optimizer grouping follows train.py:572-589: BN weights (no decay) / other .weight (decay) / .bias; parameters that are
 in no group (pos_emb, sobel_factor, frozen sobel_weight) are never stepped, as in the reference.
+
+MI355X specifics: the optimizer + EMA is ONE fused multi-tensor HIP launch with device-resident hyper-parameters, the
+dropout masks come from a device seed word, and nothing in the step synchronises with the host, so the whole step
+(~4000 kernel launches) can be captured once into a hipGraph and replayed (`graph=True`): the host then spends
+microseconds per step instead of ~175 ms enqueueing launches.  Graph mode needs a fixed batch shape and target count
+(pad the target list with rows whose image index is negative: the assignment kernel skips them).
 """
 import torch
 import torch.nn as nn
@@ -14,6 +20,9 @@ import torch.nn as nn
 from models.yolo_test import Model  # noqa: F401  (re-export for callers)
 from utils.loss import ComputeLoss
 from utils.torch_utils import ModelEMA
+
+from . import fusion_ops as F2
+from .optim import FusedSGDEMA
 
 HYP_SCRATCH = dict(lr0=0.01, lrf=0.2, momentum=0.937, weight_decay=0.0005, warmup_epochs=3.0, warmup_momentum=0.8,
                    warmup_bias_lr=0.1, box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, iou_t=0.20, anchor_t=4.0,
@@ -42,11 +51,16 @@ def param_groups(model):
     return pg0, pg1, pg2
 
 
-def build_optimizer(model, hyp, total_batch_size):
+def build_optimizer(model, hyp, total_batch_size, fused=True, ema_model=None):
     nbs = 64
     accumulate = max(round(nbs / total_batch_size), 1)
     wd = hyp['weight_decay'] * total_batch_size * accumulate / nbs                      # train.py:568-570
     pg0, pg1, pg2 = param_groups(model)
+    if fused:
+        groups = [dict(params=pg0, lr=hyp['lr0'], momentum=hyp['momentum'], weight_decay=0.0),
+                  dict(params=pg1, lr=hyp['lr0'], momentum=hyp['momentum'], weight_decay=wd),
+                  dict(params=pg2, lr=hyp['lr0'], momentum=hyp['momentum'], weight_decay=0.0)]
+        return FusedSGDEMA(model, groups, ema_model=ema_model), accumulate
     opt = torch.optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)  # train.py:585-589
     opt.add_param_group({'params': pg1, 'weight_decay': wd})
     opt.add_param_group({'params': pg2})
@@ -54,21 +68,30 @@ def build_optimizer(model, hyp, total_batch_size):
 
 
 class TrainStep:
-    def __init__(self, model, nc, imgsz, batch_size, world_size=1, reducer=None, hyp=None, ema=True, accumulate=None):
+    def __init__(self, model, nc, imgsz, batch_size, world_size=1, reducer=None, hyp=None, ema=True, accumulate=None,
+                 fused_optimizer=True, graph=False):
         self.model = model
         self.world_size = world_size
         self.reducer = reducer
         hyp = scale_hyp(HYP_SCRATCH if hyp is None else hyp, nc, imgsz)
         model.nc, model.hyp, model.gr = nc, hyp, 1.0                                    # train.py:693-695
-        self.optimizer, self.accumulate = build_optimizer(model, hyp, batch_size * world_size)
+        self.ema = ModelEMA(model) if ema else None
+        self.fused = fused_optimizer
+        self.optimizer, self.accumulate = build_optimizer(model, hyp, batch_size * world_size, fused=fused_optimizer,
+                                                          ema_model=self.ema.ema if self.ema is not None else None)
         if accumulate is not None:                                                      # e.g. 1: optimizer + EMA every batch
             self.accumulate = accumulate
-        self.ema = ModelEMA(model) if ema else None
         self.compute_loss = ComputeLoss(model)
         self.ni = 0
+        self.use_graph = graph
+        self._graph = None
+        assert not (graph and self.accumulate != 1), 'graph mode captures one full step: accumulate must be 1'
+        assert not (graph and not fused_optimizer), 'graph mode needs the fused optimizer (device-resident hyper-parameters)'
 
-    def step(self, imgs_u8, targets):
+    # ---- the step body (eager; also what gets captured) ----------------------------------------------------------------
+    def _body(self, imgs_u8, targets):
         model = self.model
+        F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
         imgs = imgs_u8.float() / 255.0                                                  # train.py:743
         rgb, ir = imgs[:, :3], imgs[:, 3:]                                              # train.py:744-745 (strided views)
         pred, comb = model(rgb, ir)                                                     # train.py:788
@@ -80,13 +103,58 @@ class TrainStep:
         loss.sum().backward()                                                           # train.py:796
         if self.reducer is not None:
             self.reducer.finish()                                                       # mean over ranks, as DDP
-        self.ni += 1
-        if self.ni % self.accumulate == 0:                                              # train.py:799-804
-            self.optimizer.step()
-            if self.reducer is not None:
-                self.reducer.zero()                                                     # grads are views of flat buckets
-            else:
-                self.optimizer.zero_grad(set_to_none=True)
-            if self.ema is not None:
-                self.ema.update(model)
         return loss, items
+
+    def _update(self, in_capture=False):
+        """train.py:799-804: optimizer step, zero_grad, EMA."""
+        if self.fused:
+            if in_capture:
+                self.optimizer.launch()          # hyper-parameters are uploaded outside the graph, before each replay
+            else:
+                self.optimizer.step()
+        else:
+            self.optimizer.step()
+            if self.ema is not None:
+                self.ema.update(self.model)
+        if self.reducer is not None:
+            self.reducer.zero()                                                         # grads are views of flat buckets
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
+    def step(self, imgs_u8, targets):
+        if self.use_graph:
+            return self._graph_step(imgs_u8, targets)
+        loss, items = self._body(imgs_u8, targets)
+        self.ni += 1
+        if self.ni % self.accumulate == 0:
+            self._update()
+        return loss, items
+
+    # ---- whole-step hipGraph -----------------------------------------------------------------------------------------------
+    def _graph_step(self, imgs_u8, targets):
+        if self._graph is None:
+            self._capture(imgs_u8, targets)
+        else:
+            assert imgs_u8.shape == self._imgs.shape and targets.shape == self._targets.shape, \
+                'graph mode: fixed batch shape and (padded) target count'
+        self._imgs.copy_(imgs_u8, non_blocking=True)
+        self._targets.copy_(targets, non_blocking=True)
+        self.optimizer.upload_hyper()
+        self._graph.replay()
+        self.ni += 1
+        return self._loss, self._items
+
+    def _capture(self, imgs_u8, targets):
+        self._imgs, self._targets = imgs_u8.clone(), targets.clone()
+        side = torch.cuda.Stream(device=imgs_u8.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up off the default stream: allocations, lazy inits,
+            for _ in range(2):                              # momentum-buffer initialisation (first-step flag)
+                self._body(self._imgs, self._targets)
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss, self._items = self._body(self._imgs, self._targets)
+            self._update(in_capture=True)

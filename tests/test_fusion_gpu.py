@@ -117,13 +117,13 @@ def test_attention_dropout_is_consistent():
     def run(qq):
         out, probs = torch.empty_like(qq), torch.empty(B, heads, 128, 128, device=d)
         lib.attention_fwd(qq.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, C // heads,
-                          C, 0.3, seed, st)
+                          C, 0.3, seed, None, st)
         return out, probs
     out, probs = run(q)
     w = torch.randn_like(out)
     dq, dk_, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), w.data_ptr(), dq.data_ptr(), dk_.data_ptr(),
-                      dv.data_ptr(), B, heads, C // heads, C, 0.3, seed, st)
+                      dv.data_ptr(), B, heads, C // heads, C, 0.3, seed, None, st)
     dirn = torch.randn_like(q)
     eps = 1e-2
     fd = ((run(q + eps * dirn)[0] - run(q - eps * dirn)[0]) * w).sum().item() / (2 * eps)
