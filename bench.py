@@ -106,7 +106,7 @@ class ConvTimer:
             return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW
         wrap('conv_fwd', lambda a: fl(a[5]))
         wrap('conv_dgrad', lambda a: fl(a[3]))
-        wrap('conv_wgrad', lambda a: fl(a[5]))
+        wrap('conv_wgrad', lambda a: fl(a[6]))
 
     def summary(self):
         """-> (total flop, union-of-intervals busy ms, {entry point: [flop, sum of launch ms, launches]})"""

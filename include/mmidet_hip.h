@@ -52,9 +52,10 @@ int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, fl
                  const mmi_conv_desc* d, void* stream);
 /* dx = conv_transpose(dy, w): gradient w.r.t. the input (autograd of the call sites above). dx has row stride ldx. */
 int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, void* stream);
-/* dw (OHWI) = sum over pixels dy^T x.  workspace holds split-K slabs; query its size first. */
+/* dw (OHWI) = sum over pixels dy^T x; dbias (nullable, Cout floats) = column sums of dy, taken from the same dy tiles
+ * (the bias gradient of Detect / Linear costs no extra pass).  workspace holds split-K slabs; query its size first. */
 size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d);
-int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
+int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                    const mmi_conv_desc* d, void* stream);
 
 /* ---- BatchNorm (training statistics) + activation (+ residual) --------------------------------------------------

@@ -19,6 +19,10 @@
 namespace {
 
 constexpr int BK = 32;
+#ifndef MMI_IGEMM_STAGES
+#define MMI_IGEMM_STAGES 1  // LDS stages of the fwd/dgrad kernel: 1 = single buffer + register prefetch (3 waves/SIMD,
+                            // measured +3 % over the double-buffered 2-waves/SIMD form); 2 = double buffer
+#endif
 constexpr int LDS_PAD = BK + 4;  // floats per [row][k] LDS row
 
 // Invalid lanes of the branch-free tile loaders read this instead of being masked afterwards: no select on the loaded
@@ -175,7 +179,7 @@ __device__ __forceinline__ f32x4 load_b_kn(const IgemmP& p, const Taps& tp, int 
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kernel(IgemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / 32;                       // A rows per loader thread
   constexpr int A_ELEMS = BM * LDS_PAD;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   constexpr int RB = BN / 32;                       // fwd: B rows per loader thread
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
-  __shared__ __align__(16) float smem[2 * STAGE];
+  __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
     // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
     // masked to the zero source, so the last iteration only stages zeros into the idle buffer.
     advance();
-    const float* As = smem + (ks & 1) * STAGE;
+    const float* As = smem + (MMI_IGEMM_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
@@ -360,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
-    lstore((ks + 1) & 1);
+    if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
+    lstore(MMI_IGEMM_STAGES == 2 ? ((ks + 1) & 1) : 0);
     __syncthreads();
   }
 
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
 struct WgradP {
   const float* DY;
   const float* X;
-  float* OUT;  // dw, or slab base when splits > 1
+  float* OUT;   // dw, or slab base when splits > 1
+  float* OUTB;  // bias gradient (column sums of dy) of split 0, or null; split z writes OUTB + z * slab_stride
   const float* zero;
   int Mpix, Cout, Cin, KH, KW, Ho, Wo, H, W, stride, pad, ldx, ldy, Ntot, chunk, mtiles, ntiles, splits;
   int64_t slab_stride;
@@ -457,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 
   f32x4 ra[ITA], rb[ITB];
   const int howo = p.Ho * p.Wo;
+  const bool want_bias = (p.OUTB != nullptr) && (nt == 0);  // uniform: the first N-tile of each (M-tile, split)
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
   // division-free pixel cursors for the B (activation) rows: pixel -> (img, oh, ow), advanced by BK per slab
   int k0cur = kbeg;
@@ -534,7 +542,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     float* As = smem + stage * STAGE;
     float* Bs = As + A_ELEMS;
 #pragma unroll
-    for (int i = 0; i < ITA; ++i) *reinterpret_cast<f32x4*>(As + (akr + RPA * i) * BM + (t % VA) * 4) = ra[i];
+    for (int i = 0; i < ITA; ++i) {
+      *reinterpret_cast<f32x4*>(As + (akr + RPA * i) * BM + (t % VA) * 4) = ra[i];
+      if (want_bias) bsum += ra[i];  // the dy tile passes through here exactly once: its column sums are the bias gradient
+    }
 #pragma unroll
     for (int i = 0; i < ITB; ++i) *reinterpret_cast<f32x4*>(Bs + (bkr + RPB * i) * BN + (t % VB) * 4) = rb[i];
   };
@@ -580,6 +591,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     __syncthreads();
   }
 
+  if (want_bias) {  // fold the RPA row-lanes of each channel quad through LDS (free after the loop's last barrier)
+    float* red = smem;  // [RPA][BM]
+    *reinterpret_cast<f32x4*>(red + akr * BM + (t % VA) * 4) = bsum;
+    __syncthreads();
+    if (t < BM && m0 + t < p.Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < RPA; ++i) s += red[i * BM + t];
+      p.OUTB[(int64_t)blockIdx.y * p.slab_stride + m0 + t] = s;
+    }
+  }
   float* out = p.OUT + (int64_t)blockIdx.y * p.slab_stride;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -597,10 +619,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 }
 
 // out = sum over splits of slabs[z]: 16-byte lanes, 4 independent loads in flight per thread (HBM-bound)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int64_t n, int splits) {
+// (elements [0, n1) go to out, the bias tail [n1, n) to out2)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, float* __restrict__ out2,
+                                   int64_t n1, int64_t n, int64_t count, int splits) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 4 <= n && (n & 3) == 0) {
+  if (i >= count) return;  // count = n (with the bias tail) or n1 (without); n is the slab stride
+  if (i + 4 <= n1 && (n & 3) == 0) {
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int z = 0;
     for (; z + 4 <= splits; z += 4) {
@@ -612,10 +636,11 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     for (; z < splits; ++z) s0 += *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * n + i);
     *reinterpret_cast<f32x4*>(out + i) = (s0 + s1) + (s2 + s3);
   } else {
-    for (int64_t j = i; j < n && j < i + 4; ++j) {
+    for (int64_t j = i; j < count && j < i + 4; ++j) {
       float s = 0.f;
       for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * n + j];
-      out[j] = s;
+      if (j < n1) out[j] = s;
+      else out2[j - n1] = s;
     }
   }
 }
@@ -736,10 +761,19 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   g.mtiles = cdiv(d->Cout, g.bm);
   g.ntiles = cdiv(Ntot, g.bn);
   const int tiles = g.mtiles * g.ntiles;
-  int splits = cdiv(768, tiles);                                    // ~3 workgroups per CU
+  // Split K (pixels) so that tiles*splits fills whole waves of the 512 resident workgroups (2 per CU): a grid of 1.5
+  // waves wastes a quarter of the chip.  Fewer splits win ties (less slab traffic).
   const int max_splits = (int)((Mpix + 511) / 512);                 // >= 512 pixels (16 K-steps) per split
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  int cap = tiles > 64 ? 16 : cdiv(1024, tiles);
+  if (cap > max_splits) cap = max_splits;
+  if (cap < 1) cap = 1;
+  int splits = 1;
+  double best = 0.0;
+  for (int sp = 1; sp <= cap; ++sp) {
+    const int blocks = tiles * sp;
+    const double eff = (double)blocks / (double)(cdiv(blocks, 512) * 512);
+    if (eff > best + 1e-9) best = eff, splits = sp;
+  }
   g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;
   g.splits = cdiv(Mpix, g.chunk);
   return g;
@@ -749,22 +783,24 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
 extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_wgrad_workspace") != MMI_OK) return 0;
   const WgPlan g = wgrad_plan(d);
-  return g.splits > 1 ? (size_t)g.splits * d->Cout * d->KH * d->KW * d->Cin * sizeof(float) : 0;
+  return g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
 }
 
-extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes,
-                              const mmi_conv_desc* d, void* stream) {
+extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
+                              size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
   const WgPlan g = wgrad_plan(d);
   MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
   const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;
-  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.splits * wsize * sizeof(float))) {
-    mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)g.splits * wsize * sizeof(float));
+  const int64_t slab = wsize + d->Cout;  // weight gradient + bias-gradient tail
+  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.splits * slab * sizeof(float))) {
+    mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)g.splits * slab * sizeof(float));
     return MMI_ERR_WORKSPACE;
   }
   WgradP p{};
   p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? (float*)workspace : dw;
+  p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? (float*)workspace + wsize : dbias);
   p.zero = zero_src();
   if (p.zero == nullptr) {
     mmi_set_error("mmi_conv_wgrad: cannot resolve the zero-source symbol");
@@ -773,7 +809,7 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* 
   p.Mpix = d->N * d->Ho * d->Wo; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.Ho = d->Ho; p.Wo = d->Wo; p.H = d->H; p.W = d->W; p.stride = d->stride; p.pad = d->pad;
   p.ldx = d->ldx; p.ldy = d->ldy; p.Ntot = d->KH * d->KW * d->Cin; p.chunk = g.chunk;
-  p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = wsize;
+  p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = g.splits > 1 ? slab : 0;
   const dim3 grid(g.mtiles * g.ntiles, g.splits), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
@@ -786,7 +822,10 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, void* 
 #undef LAUNCHW
   MMI_CHECK_LAUNCH("mmi_conv_wgrad");
   if (g.splits > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(wsize, 1024)), dim3(256), 0, s, (const float*)workspace, dw, wsize, g.splits);
+    // without dbias only the weight part [0, wsize) of every slab is reduced
+    const int64_t count = dbias != nullptr ? slab : wsize;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, s, (const float*)workspace, dw, dbias, wsize, slab, count,
+                       g.splits);
     MMI_CHECK_LAUNCH("mmi_conv_wgrad(reduce)");
   }
   return MMI_OK;

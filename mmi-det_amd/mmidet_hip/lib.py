@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- must come first: torch brings its own libamdhip64
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libmmidet_hip.so')
+LIB_PATH = os.environ.get('MMIDET_HIP_LIB', os.path.join(CSRC, 'libmmidet_hip.so'))  # override: kernel A/B experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError('%s is missing: the HIP extension is not built (run `python __graft_entry__.py` or '
@@ -32,7 +32,7 @@ _SIGS = {
     'mmi_conv_fwd': (c_int, [P, P, P, P, P, POINTER(ConvDesc), P]),
     'mmi_conv_dgrad': (c_int, [P, P, P, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
-    'mmi_conv_wgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
     'mmi_bn_eval_stats': (c_int, [P, P, c_int, c_float, P, P]),
     'mmi_bn_act_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, c_int64, c_int, c_int, P]),

@@ -14,9 +14,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def scratch(nfloats, device, slot=0):
-    """Grow-only fp32 workspace per (device, slot).  Safe to share: all kernels of a step run on one stream in order."""
-    key = (device, slot)
+def scratch(nfloats, device, slot=0, stream=None):
+    """Grow-only fp32 workspace per (device, slot, stream): kernels on one stream run in order, so a stream may reuse its
+    buffer for every call; the two backbone lanes and the wgrad side streams each get their own."""
+    key = (device, slot, _stream() if stream is None else stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
@@ -74,31 +75,35 @@ _side_streams = {}
 
 
 def _side_stream(device):
-    s = _side_streams.get(device)
+    """The wgrad companion of the CURRENT stream (each backbone lane has its own)."""
+    key = (device, _stream())
+    s = _side_streams.get(key)
     if s is None:
         s = torch.cuda.Stream(device=device)
-        _side_streams[device] = s
+        _side_streams[key] = s
     return s
 
 
-def _wgrad(dy, lddy, x, ldx, w, d, overlap=False):
+def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False):
     """dw = dy^T x.  With overlap=True the kernel is enqueued on the side stream behind everything already on the
     current stream; the caller must `_join_side()` before the current stream (or anyone else) touches dw.  dgrad and wgrad
     of one layer are independent, and two co-running grids fill each other's partial last wave (the fp32-MFMA kernels
     lose up to a third of the chip to wave quantisation when they run alone)."""
     dw = torch.empty_strided(w.shape, w.stride(), dtype=w.dtype, device=w.device)
+    db = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if want_bias else None
+    dbp = db.data_ptr() if want_bias else None
     nbytes = lib.conv_wgrad_workspace(d)
     if overlap:
         main, side = torch.cuda.current_stream(), _side_stream(w.device)
-        ws = scratch(nbytes // 4, w.device, slot=4) if nbytes else None
+        ws = scratch(nbytes // 4, w.device, slot=4, stream=side.cuda_stream) if nbytes else None
         side.wait_stream(main)
-        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
-                       side.cuda_stream)
+        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
+                       d, side.cuda_stream)
     else:
         ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
-        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, d,
-                       _stream())
-    return dw
+        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
+                       d, _stream())
+    return (dw, db) if want_bias else dw
 
 
 def _join_side(device):
@@ -203,15 +208,18 @@ class _ConvBias(Function):
         dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, lddy)
         dx = None
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-        dw = None
+        dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dwd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.ldx, lddy)
-            dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
+            if want_db:   # the bias gradient falls out of the weight-gradient kernel's dy tiles
+                dw, db = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both, want_bias=True)
+            else:
+                dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
             lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
-        db = None
-        if has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
             db = torch.empty(d.Cout, dtype=x.dtype, device=x.device)
             part = scratch(lib.bn_bwd_parts(rows) * d.Cout, x.device)

@@ -9,6 +9,7 @@ Reference behaviours deliberately NOT reproduced: per-forward prints (yolo_test.
 """
 import logging
 import math
+import os
 from copy import deepcopy
 from pathlib import Path
 
@@ -24,6 +25,16 @@ from utils.general import make_divisible
 from utils.torch_utils import initialize_weights, model_info
 
 logger = logging.getLogger(__name__)
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        return [obj]
+    if isinstance(obj, FusedTokens):
+        return list(obj.maps)
+    if isinstance(obj, (list, tuple)):
+        return [t for o in obj for t in _tensors_of(o)]
+    return []
 
 
 class Upsample2x(nn.Upsample):
@@ -100,6 +111,39 @@ class Model(nn.Module):
             self._initialize_biases()
         initialize_weights(self)
         self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = self.Combine_loss = torch.zeros(0)
+        self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
+        self._plan_lanes()
+
+    def _plan_lanes(self):
+        """Static lane plan: lane[i] is True for layers of the IR backbone (fed by `from=-4` and by single-input layers /
+        Add2 that continue an IR tensor); everything that mixes the streams stays on the caller's stream."""
+        lanes, srcs = [], []
+        for m in self.model:
+            i, f = m.i, m.f
+            if f == -4:
+                lanes.append(True)
+                srcs.append([])
+                continue
+            fl = [f] if isinstance(f, int) else list(f)
+            src = [(i - 1 if j == -1 else (j if j >= 0 else i + j)) for j in fl]
+            src = [j for j in src if j >= 0]
+            if isinstance(m, Add2):
+                lane = lanes[src[0]]
+            elif isinstance(f, int):
+                lane = lanes[src[0]] if src else False
+            else:
+                lane = False
+            lanes.append(lane)
+            srcs.append(src)
+        self._lanes, self._srcs = lanes, srcs
+        self._ir_streams = {}
+
+    def _ir_stream(self, device):
+        s = self._ir_streams.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            self._ir_streams[device] = s
+        return s
 
     def forward(self, x, x2, augment=False, profile=False):
         if augment:
@@ -112,11 +156,31 @@ class Model(nn.Module):
         self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = empty
         x = ops.nchw_to_nhwc(x)
         x2 = ops.nchw_to_nhwc(x2)
+        # The twin backbones are independent between fusion points: the IR lane runs on its own HIP stream so that its
+        # kernels fill the partial last wave of the RGB lane's (and vice versa); autograd replays the same streams in
+        # backward.  Events order every cross-lane hand-off.
+        lanes = self._lanes if (self.two_streams and x.is_cuda) else None
+        main = torch.cuda.current_stream() if lanes else None
+        if lanes:
+            ir = self._ir_stream(dev)
+            ir.wait_stream(main)
+            x2.record_stream(ir)
+            done = {}
         x = self.Enhance(x)                                        # CEM on the RGB stream only
         y = []
+        prev = x
         for m in self.model:
             if m.f != -1 and m.f != -4:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            if lanes:
+                st_ = ir if lanes[m.i] else main
+                for j in self._srcs[m.i]:                          # hand-offs from the other lane
+                    if lanes[j] != lanes[m.i]:
+                        st_.wait_event(done[j])
+                        for t in _tensors_of(y[j] if y[j] is not None else prev):   # unsaved => j is the previous layer
+                            t.record_stream(st_)
+                ctx = torch.cuda.stream(st_)
+                ctx.__enter__()
             if m.f == -4:
                 x = m(x2)
             elif isinstance(m, GPT1_fourier):
@@ -127,7 +191,15 @@ class Model(nn.Module):
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
                 x = m(x)
+            if lanes:
+                ev = torch.cuda.Event()
+                ev.record(st_)
+                done[m.i] = ev
+                ctx.__exit__(None, None, None)
+            prev = x
             y.append(x if m.i in self.save else None)
+        if lanes:
+            main.wait_stream(ir)
         self.Combine_loss = self.SSIMloss                          # yolo_test.py:266-268 (detached SSIM term)
         return x, self.Combine_loss
 

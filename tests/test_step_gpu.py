@@ -112,7 +112,8 @@ def test_whole_step_graph_matches_eager():
         close(i1, i2, what='items', tol=2e-3)
     w1, w2 = m1.model[1].conv.weight, m2.model[1].conv.weight
     close(w1, w2, what='weights after 4 graph replays', tol=2e-3)
-    close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=2e-4)
+    # (with d = 0.9999*(1-exp(-n/2000)) ~ 0.003 after 6 updates the EMA is almost the latest weights: same tolerance)
+    close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=2e-3)
 
 
 def test_graph_replay_draws_fresh_dropout_masks():

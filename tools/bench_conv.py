@@ -45,7 +45,7 @@ def main():
         fl = 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k
         t1 = timeit(lambda: lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), desc, st))
         t2 = timeit(lambda: lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), desc, st))
-        t3 = timeit(lambda: lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, desc, st))
+        t3 = timeit(lambda: lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st))
         print('%-34s %9.1f %9.1f %9.1f   (%.3f %.3f %.3f)' % (str((B, H, W, Ci, Co, k, s)), fl / t1 / 1e9, fl / t2 / 1e9,
                                                                 fl / t3 / 1e9, t1, t2, t3), flush=True)
 

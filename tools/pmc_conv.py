@@ -23,6 +23,6 @@ part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Co, device=d)
 for _ in range(3):
     lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), desc, st)
     lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), desc, st)
-    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, desc, st)
+    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
 torch.cuda.synchronize()
 print('flop per launch', 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k)
