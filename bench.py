@@ -66,6 +66,7 @@ class ConvTimer:
 
     def __init__(self):
         self.recs = []
+        self.shapes = []
         self.on = False
         self.ref = None
         self._streams = {}
@@ -99,6 +100,8 @@ class ConvTimer:
                 r = fn(*a)
                 e.record(st)
                 timer.recs.append((name, flops_of(a), s, e))
+                dd = [x for x in a if hasattr(x, 'Cout')][0]
+                timer.shapes.append((dd.N, dd.H, dd.W, dd.Cin, dd.Cout, dd.KH, dd.stride))
                 return r
             setattr(lib, name, timed)
 
@@ -107,6 +110,18 @@ class ConvTimer:
         wrap('conv_fwd', lambda a: fl(a[5]))
         wrap('conv_dgrad', lambda a: fl(a[3]))
         wrap('conv_wgrad', lambda a: fl(a[6]))
+
+    def by_shape(self):
+        """[(entry point, shape) -> launches, ms, TFLOP/s] sorted by time: where the GEMM time goes."""
+        agg = {}
+        for (name, f, s, e), shp in zip(self.recs, self.shapes):
+            v = agg.setdefault((name, shp), [0, 0.0, 0.0])
+            v[0] += 1
+            v[1] += s.elapsed_time(e)
+            v[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return ['%-11s N%-5d %4dx%-4d %5d->%-5d k%d s%d  x%-4d %8.2f ms  %6.1f TF' %
+                (k[0], *k[1], v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in rows]
 
     def summary(self):
         """-> (total flop, union-of-intervals busy ms, {entry point: [flop, sum of launch ms, launches]})"""
@@ -201,6 +216,7 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-gemm', default=None, help='write the per-shape GEMM time table of the roofline pass here')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
 
@@ -305,6 +321,9 @@ def main():
         }
         if not args.no_roofline:
             tot_f, tot_ms, per = timer.summary()
+            if args.dump_gemm:
+                with open(args.dump_gemm, 'w') as fh:
+                    fh.write('\n'.join(timer.by_shape()) + '\n')
             ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,

@@ -86,6 +86,17 @@ int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, co
                          const float* gamma, const float* beta, const float* partials, int nparts, float* dy, int lddy,
                          float* dgamma, float* dbeta, int64_t rows, int C, int act, int frozen, void* stream);
 
+/* ---- Contour Enhancement Module special forms (models/common.py:751-911) --------------------------------------------
+ * The 3->24 and 24->3 convs of AdaptiveModule3 are served by mmi_conv_fwd/dgrad/wgrad themselves (direct VALU kernels,
+ * selected by the descriptor).  The 24->24 EnhanceConv2d never runs as a convolution:
+ *   t[pix][o] = r[pix][o] + factor[o] * stencil_{o%8}(sum_c r[pix][c]) + bias[o]      (common.py:795, 899-909)
+ * chansum (N*H*W floats) is written by the forward and is all the backward needs besides dt. */
+int mmi_sobel_add_fwd(const float* r, int ldr, const float* factor, const float* bias, float* chansum, float* t, int ldt,
+                      int N, int H, int W, int C, void* stream);
+size_t mmi_sobel_add_bwd_workspace(int N, int H, int W, int C);
+int mmi_sobel_add_bwd(const float* dt, int ldd, const float* chansum, const float* factor, float* dr, int lddr,
+                      float* dfactor, float* dbias, void* workspace, int N, int H, int W, int C, void* stream);
+
 /* out[c] = sum_r x[r,c] (bias gradients of Detect / Linear).  partials: workspace of mmi_bn_bwd_parts(rows)*C floats. */
 int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream);
 

@@ -347,3 +347,12 @@ extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* p
   MMI_CHECK_LAUNCH("mmi_colsum(finalize)");
   return MMI_OK;
 }
+
+// library-internal (common.h): partials[part][2][C] -> out0 = sum of slot 0, out1 = sum of slot 1, folded in fp64
+int mmi_pair_colsum(const float* partials, int nparts, int C, float* out0, float* out1, void* stream) {
+  MMI_CHECK_ARG(partials && out0 && out1 && nparts > 0 && C > 0, "mmi_pair_colsum: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, out1,
+                     out0);
+  MMI_CHECK_LAUNCH("mmi_pair_colsum");
+  return MMI_OK;
+}

@@ -1,0 +1,393 @@
+// Contour Enhancement Module kernels: the full-resolution 3->24->3 channel path of
+// AdaptiveModule3 / EnhanceConv2d (models/common.py:751-911 of the reference).  With 3 or 24 channels an MFMA tile is
+// 3/64 .. 24/64 occupied (the generic implicit GEMM ran these layers at 1-12 TFLOP/s, ~21 ms per step); here they are
+// direct VALU convolutions with the 648 weights held in scalar registers, and the 24->24 "Sobel bank" conv is never
+// materialised at all: every one of its 24 output channels is  factor[o] * stencil_{o%8}(sum_c r_c) + bias[o],  i.e. eight
+// fixed 3x3 stencils of ONE channel-sum map, which is a memory-bound elementwise op (and so is its backward).
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;  // 16x16 pixel tile per 256-thread workgroup
+
+// out[pix][o] = sum_{tap,c} in[pix + tap - 1][c] * Wsel(o, tap, c)  (+ bias[o]); 3x3, stride 1, zero pad 1, NHWC.
+//   TRANSPOSED = false: forward conv,  Wsel(o,tap,c) = w[(o*9 + tap)*CIN + c]            (w is OHWI [COUT][9][CIN])
+//   TRANSPOSED = true : data gradient, Wsel(o,tap,c) = w[(c*9 + 8 - tap)*COUT + o]       (w is OHWI [CIN][9][COUT])
+// Weight indices are compile-time after unrolling and the pointer is uniform: hipcc keeps the weights in SGPRs.
+template <int CIN, int COUT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void smallconv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int ldy,
+                                                        float* __restrict__ stat_part, int H, int W) {
+  const int tx = threadIdx.x & (TS - 1), ty = threadIdx.x >> 4;
+  const int ow = blockIdx.x * TS + tx, oh = blockIdx.y * TS + ty, n = blockIdx.z;
+  const bool live = ow < W && oh < H;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+    if (live && ih >= 0 && iw >= 0 && ih < H && iw < W) {
+      const float* src = x + (((int64_t)n * H + ih) * W + iw) * ldx;
+      float xin[CIN];
+      if (CIN % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < CIN; c += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+          xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) xin[c] = src[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+          acc[o] += xin[c] * (TRANSPOSED ? w[(c * 9 + 8 - tap) * COUT + o] : w[(o * 9 + tap) * CIN + c]);
+    }
+  }
+  if (bias != nullptr) {
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] += bias[o];
+  }
+  if (live) {
+    float* dst = y + (((int64_t)n * H + oh) * W + ow) * ldy;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) dst[o] = acc[o];
+  }
+  if (stat_part != nullptr) {  // BatchNorm batch statistics: per-block column sums of y and y*y
+    __shared__ float red[2][4][COUT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      float s1 = live ? acc[o] : 0.f, s2 = s1 * s1;
+#pragma unroll
+      for (int k = 32; k > 0; k >>= 1) {
+        s1 += __shfl_xor(s1, k);
+        s2 += __shfl_xor(s2, k);
+      }
+      if (lane == 0) {
+        red[0][wv][o] = s1;
+        red[1][wv][o] = s2;
+      }
+    }
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x < 2 * COUT) {
+      const int s = threadIdx.x / COUT, o = threadIdx.x - s * COUT;
+      stat_part[((int64_t)blk * 2 + s) * COUT + o] = red[s][0][o] + red[s][1][o] + red[s][2][o] + red[s][3][o];
+    }
+  }
+}
+
+// dW[co][tap][ci] = sum_pix dy[pix][co] * x[pix + tap - 1][ci]; each workgroup walks 16x16 pixel tiles with x (haloed)
+// and dy staged in LDS, every thread owning up to 3 of the COUT*9*CIN outputs; per-workgroup partials, summed afterwards.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ dy, int ldy,
+                                                              float* __restrict__ partials, int N, int H, int W) {
+  constexpr int NOUT = COUT * 9 * CIN, PER = (NOUT + 255) / 256;
+  __shared__ float xs[(TS + 2) * (TS + 2) * CIN];
+  __shared__ float ds[TS * TS * COUT];
+  const int t = threadIdx.x;
+  int o_co[PER], o_off[PER], o_ci[PER];
+  bool o_ok[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int o = t + 256 * j;
+    o_ok[j] = o < NOUT;
+    const int oo = o_ok[j] ? o : 0;
+    o_co[j] = oo / (9 * CIN);
+    const int r = oo - o_co[j] * 9 * CIN, tap = r / CIN;
+    o_ci[j] = r - tap * CIN;
+    o_off[j] = ((tap / 3) * (TS + 2) + tap % 3) * CIN + o_ci[j];  // xs offset of the tap relative to the pixel
+  }
+  float acc[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+  const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
+  const int ntiles = tw * th * N;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tw * th), r = tile - n * tw * th;
+    const int h0 = (r / tw) * TS, w0 = (r % tw) * TS;
+    __syncthreads();
+    for (int e = t; e < (TS + 2) * (TS + 2) * CIN; e += 256) {
+      const int c = e % CIN, p = e / CIN;
+      const int ih = h0 + p / (TS + 2) - 1, iw = w0 + p % (TS + 2) - 1;
+      xs[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? x[(((int64_t)n * H + ih) * W + iw) * ldx + c] : 0.f;
+    }
+    for (int e = t; e < TS * TS * COUT; e += 256) {
+      const int c = e % COUT, p = e / COUT;
+      const int oh = h0 + p / TS, ow = w0 + p % TS;
+      ds[e] = (oh < H && ow < W) ? dy[(((int64_t)n * H + oh) * W + ow) * ldy + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < TS * TS; ++p) {
+      const int base = ((p / TS) * (TS + 2) + p % TS) * CIN;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) acc[j] += ds[p * COUT + o_co[j]] * xs[base + o_off[j]];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+    if (o_ok[j]) partials[(int64_t)blockIdx.x * NOUT + t + 256 * j] = acc[j];
+}
+
+__global__ void rowsum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += (double)partials[(int64_t)p * n + i];
+  out[i] = (float)s;
+}
+
+// ---- the stencil bank of EnhanceConv2d (models/common.py:838-882), index = out_channel % 8 ---------------------------
+__device__ __forceinline__ void stencils8(const float r[9], float s[8]) {
+  // r = 3x3 neighbourhood of the channel-sum map, row-major (r[4] = centre)
+  s[0] = -r[0] - 2.f * r[1] - r[2] + r[6] + 2.f * r[7] + r[8];
+  s[1] = -r[0] + r[2] - 2.f * r[3] + 2.f * r[5] - r[6] + r[8];
+  s[2] = -2.f * r[0] - r[1] - r[3] + r[5] + r[7] + 2.f * r[8];
+  s[3] = s[2];  // the reference's second diagonal branch is identical (common.py:849-862)
+  s[4] = r[1] + r[3] - 4.f * r[4] + r[5] + r[7];
+  s[5] = r[1] + r[3] + 4.f * r[4] + r[5] + r[7];
+  s[6] = -r[0] - r[1] - r[2] + r[6] + r[7] + r[8];
+  s[7] = -r[0] + r[2] - r[3] + r[5] - r[6] + r[8];
+}
+// transpose: contribution of D_k at neighbour offset d to the centre = stencil_k[-d] * D_k; given the 3x3 neighbourhood
+// dn[k][9] of the eight D maps, returns sum_k sum_d stencil_k[8-d] * dn[k][d]
+__device__ __forceinline__ float stencils8_t(const float dn[8][9]) {
+  float a = 0.f;
+  const float* d;
+  d = dn[0]; a += -d[8] - 2.f * d[7] - d[6] + d[2] + 2.f * d[1] + d[0];
+  d = dn[1]; a += -d[8] + d[6] - 2.f * d[5] + 2.f * d[3] - d[2] + d[0];
+  d = dn[2]; a += -2.f * d[8] - d[7] - d[5] + d[3] + d[1] + 2.f * d[0];
+  d = dn[3]; a += -2.f * d[8] - d[7] - d[5] + d[3] + d[1] + 2.f * d[0];
+  d = dn[4]; a += d[7] + d[5] - 4.f * d[4] + d[3] + d[1];
+  d = dn[5]; a += d[7] + d[5] + 4.f * d[4] + d[3] + d[1];
+  d = dn[6]; a += -d[8] - d[7] - d[6] + d[2] + d[1] + d[0];
+  d = dn[7]; a += -d[8] + d[6] - d[5] + d[3] - d[2] + d[0];
+  return a;
+}
+
+template <int C>
+__global__ void chansum_kernel(const float* __restrict__ r, int ldr, float* __restrict__ R, int64_t npix) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const float* src = r + p * ldr;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  R[p] = s;
+}
+
+__device__ __forceinline__ void load9(const float* __restrict__ R, int n, int h, int w, int H, int W, float r[9]) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int ih = h + k / 3 - 1, iw = w + k % 3 - 1;
+    r[k] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? R[((int64_t)n * H + ih) * W + iw] : 0.f;
+  }
+}
+
+// t[pix][o] = r[pix][o] + factor[o] * stencil_{o%8}(R)(pix) + bias[o]
+template <int C>
+__global__ void sobel_add_fwd_kernel(const float* __restrict__ r, int ldr, const float* __restrict__ R,
+                                     const float* __restrict__ factor, const float* __restrict__ bias,
+                                     float* __restrict__ t, int ldt, int N, int H, int W) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)N * H * W) return;
+  const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+  float nb[9], s[8];
+  load9(R, n, h, w, H, W, nb);
+  stencils8(nb, s);
+  const float* src = r + p * ldr;
+  float* dst = t + p * ldt;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = v[k] + factor[c + k] * s[(c + k) & 7] + bias[c + k];
+    *reinterpret_cast<f32x4*>(dst + c) = o;
+  }
+}
+
+// backward pass 1: D[pix][k] = sum_{o%8==k} factor[o]*dt[pix][o]; partial sums of dbias[o] = sum dt_o and
+// dfactor[o] = sum dt_o * stencil_{o%8}(R): partials[block][2][C]
+template <int C>
+__global__ __launch_bounds__(256) void sobel_bwd1_kernel(const float* __restrict__ dt, int ldd, const float* __restrict__ R,
+                                                         const float* __restrict__ factor, float* __restrict__ D,
+                                                         float* __restrict__ partials, int N, int H, int W) {
+  __shared__ float red[2][4][C];
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < (int64_t)N * H * W;
+  float db[C], df[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) db[c] = df[c] = 0.f;
+  if (live) {
+    const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+    float nb[9], s[8], dk[8];
+    load9(R, n, h, w, H, W, nb);
+    stencils8(nb, s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dk[k] = 0.f;
+    const float* src = dt + p * ldd;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        db[c + k] = v[k];
+        df[c + k] = v[k] * s[(c + k) & 7];
+        dk[(c + k) & 7] += factor[c + k] * v[k];
+      }
+    }
+    f32x4 d0 = {dk[0], dk[1], dk[2], dk[3]}, d1 = {dk[4], dk[5], dk[6], dk[7]};
+    *reinterpret_cast<f32x4*>(D + p * 8) = d0;
+    *reinterpret_cast<f32x4*>(D + p * 8 + 4) = d1;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float a = db[c], b = df[c];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+      a += __shfl_xor(a, k);
+      b += __shfl_xor(b, k);
+    }
+    if (lane == 0) {
+      red[0][wv][c] = a;
+      red[1][wv][c] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const int s = threadIdx.x / C, c = threadIdx.x - s * C;
+    partials[((int64_t)blockIdx.x * 2 + s) * C + c] = red[s][0][c] + red[s][1][c] + red[s][2][c] + red[s][3][c];
+  }
+}
+
+// backward pass 2: dr[pix][c] = dt[pix][c] + sum_k stencil_k^T(D_k)(pix)
+template <int C>
+__global__ void sobel_bwd2_kernel(const float* __restrict__ dt, int ldd, const float* __restrict__ D, float* __restrict__ dr,
+                                  int lddr, int N, int H, int W) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)N * H * W) return;
+  const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+  float dn[8][9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int ih = h + q / 3 - 1, iw = w + q % 3 - 1;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (ih >= 0 && iw >= 0 && ih < H && iw < W) {
+      const float* src = D + (((int64_t)n * H + ih) * W + iw) * 8;
+      a = *reinterpret_cast<const f32x4*>(src);
+      b = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dn[k][q] = a[k];
+      dn[4 + k][q] = b[k];
+    }
+  }
+  const float add = stencils8_t(dn);
+  const float* src = dt + p * ldd;
+  float* dst = dr + p * lddr;
+#pragma unroll
+  for (int c = 0; c < C; c += 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += add;
+    *reinterpret_cast<f32x4*>(dst + c) = v;
+  }
+}
+
+}  // namespace
+
+// ---- dispatch helpers used by igemm.hip's public conv entry points ------------------------------------------------------
+bool mmi_smallconv_supported(const mmi_conv_desc* d) {
+  const bool a = d->Cin == 3 && d->Cout == 24, b = d->Cin == 24 && d->Cout == 3;
+  return (a || b) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && (d->Cin != 24 || d->ldx % 4 == 0);
+}
+int mmi_smallconv_blocks(const mmi_conv_desc* d) { return cdiv(d->W, TS) * cdiv(d->H, TS) * d->N; }
+
+int mmi_smallconv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_part, const mmi_conv_desc* d,
+                      hipStream_t s) {
+  const dim3 grid(cdiv(d->W, TS), cdiv(d->H, TS), d->N), block(256);
+  if (d->Cin == 3)
+    hipLaunchKernelGGL((smallconv_kernel<3, 24, false>), grid, block, 0, s, x, d->ldx, w, bias, y, d->ldy, stat_part, d->H, d->W);
+  else
+    hipLaunchKernelGGL((smallconv_kernel<24, 3, false>), grid, block, 0, s, x, d->ldx, w, bias, y, d->ldy, stat_part, d->H, d->W);
+  MMI_CHECK_LAUNCH("mmi_conv_fwd(small-channel)");
+  return MMI_OK;
+}
+
+// dx (Cin channels) from dy (Cout channels): only the 24-channel input needs it (the 3-channel one is the image)
+bool mmi_smallconv_dgrad_supported(const mmi_conv_desc* d) { return mmi_smallconv_supported(d) && d->Cin == 24; }
+int mmi_smallconv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, hipStream_t s) {
+  const dim3 grid(cdiv(d->W, TS), cdiv(d->H, TS), d->N), block(256);
+  hipLaunchKernelGGL((smallconv_kernel<3, 24, true>), grid, block, 0, s, dy, d->ldy, w, (const float*)nullptr, dx, d->ldx,
+                     (float*)nullptr, d->H, d->W);
+  MMI_CHECK_LAUNCH("mmi_conv_dgrad(small-channel)");
+  return MMI_OK;
+}
+
+constexpr int WG_BLOCKS = 2048;
+size_t mmi_smallconv_wgrad_workspace(const mmi_conv_desc* d) {
+  const int blocks = mmi_smallconv_blocks(d) < WG_BLOCKS ? mmi_smallconv_blocks(d) : WG_BLOCKS;
+  return (size_t)blocks * d->Cout * 9 * d->Cin * sizeof(float);
+}
+int mmi_smallconv_wgrad(const float* dy, const float* x, float* dw, void* workspace, const mmi_conv_desc* d, hipStream_t s) {
+  const int blocks = mmi_smallconv_blocks(d) < WG_BLOCKS ? mmi_smallconv_blocks(d) : WG_BLOCKS;
+  const int nout = d->Cout * 9 * d->Cin;
+  float* part = (float*)workspace;
+  if (d->Cin == 3)
+    hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+  else
+    hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+  MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel)");
+  hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)part, blocks, nout, dw);
+  MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel reduce)");
+  return MMI_OK;
+}
+
+// ---- public: the stencil bank as an elementwise op -----------------------------------------------------------------------
+extern "C" int mmi_sobel_add_fwd(const float* r, int ldr, const float* factor, const float* bias, float* chansum, float* t,
+                                 int ldt, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(r && factor && bias && chansum && t && N > 0 && H > 0 && W > 0, "mmi_sobel_add_fwd: bad arguments");
+  MMI_CHECK_ARG(C == 24 && ldr % 4 == 0 && ldt % 4 == 0, "mmi_sobel_add_fwd: the stencil bank is the 24-channel CEM one");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)N * H * W;
+  hipLaunchKernelGGL(chansum_kernel<24>, dim3(cdiv(npix, 256)), dim3(256), 0, s, r, ldr, chansum, npix);
+  MMI_CHECK_LAUNCH("mmi_sobel_add_fwd(chansum)");
+  hipLaunchKernelGGL(sobel_add_fwd_kernel<24>, dim3(cdiv(npix, 256)), dim3(256), 0, s, r, ldr, (const float*)chansum, factor,
+                     bias, t, ldt, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_sobel_add_fwd");
+  return MMI_OK;
+}
+
+extern "C" size_t mmi_sobel_add_bwd_workspace(int N, int H, int W, int C) {
+  const int64_t npix = (int64_t)N * H * W;
+  return (size_t)(npix * 8 + (int64_t)cdiv(npix, 256) * 2 * C) * sizeof(float);
+}
+
+extern "C" int mmi_sobel_add_bwd(const float* dt, int ldd, const float* chansum, const float* factor, float* dr, int lddr,
+                                 float* dfactor, float* dbias, void* workspace, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(dt && chansum && factor && dr && dfactor && dbias && workspace && N > 0 && H > 0 && W > 0,
+                "mmi_sobel_add_bwd: bad arguments");
+  MMI_CHECK_ARG(C == 24 && ldd % 4 == 0 && lddr % 4 == 0, "mmi_sobel_add_bwd: the stencil bank is the 24-channel CEM one");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)N * H * W;
+  const int blocks = cdiv(npix, 256);
+  float* D = (float*)workspace;
+  float* part = D + npix * 8;
+  hipLaunchKernelGGL(sobel_bwd1_kernel<24>, dim3(blocks), dim3(256), 0, s, dt, ldd, chansum, factor, D, part, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_sobel_add_bwd(1)");
+  hipLaunchKernelGGL(sobel_bwd2_kernel<24>, dim3(blocks), dim3(256), 0, s, dt, ldd, (const float*)D, dr, lddr, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_sobel_add_bwd(2)");
+  return mmi_pair_colsum(part, blocks, C, dbias, dfactor, stream);  // partials[block][2][C] -> dbias (slot 0), dfactor (slot 1)
+}

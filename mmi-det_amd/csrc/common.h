@@ -32,6 +32,19 @@ void mmi_set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- library-internal cross-file helpers (not part of the C ABI) ----------------------------------------------------
+// bn.hip: fp64 fold of partials[part][2][C] into out0[C] (slot 0) and out1[C] (slot 1)
+int mmi_pair_colsum(const float* partials, int nparts, int C, float* out0, float* out1, void* stream);
+// cem.hip: direct VALU convolutions for the 3<->24-channel CEM layers, reached through the public conv entry points
+bool mmi_smallconv_supported(const mmi_conv_desc* d);
+bool mmi_smallconv_dgrad_supported(const mmi_conv_desc* d);
+int mmi_smallconv_blocks(const mmi_conv_desc* d);
+int mmi_smallconv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_part, const mmi_conv_desc* d,
+                      hipStream_t s);
+int mmi_smallconv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, hipStream_t s);
+size_t mmi_smallconv_wgrad_workspace(const mmi_conv_desc* d);
+int mmi_smallconv_wgrad(const float* dy, const float* x, float* dw, void* workspace, const mmi_conv_desc* d, hipStream_t s);
+
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (observed round-robin), so give
 // each XCD a contiguous chunk of the tile sequence; neighbouring tiles (same activation rows, all output-channel
 // tiles) then hit the same 4 MiB L2.  Speed only, never correctness.

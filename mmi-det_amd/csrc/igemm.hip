@@ -708,6 +708,7 @@ bool fwd_vec(const mmi_conv_desc* d) { return d->Cin % 4 == 0 && d->ldx % 4 == 0
 
 extern "C" int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_fwd_row_blocks") != MMI_OK) return MMI_ERR_ARG;
+  if (mmi_smallconv_supported(d)) return mmi_smallconv_blocks(d);  // CEM layers: direct VALU conv (cem.hip)
   return fwd_plan(d, fwd_vec(d)).mtiles;
 }
 
@@ -716,6 +717,10 @@ extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, f
   if (int e = check_desc(d, "mmi_conv_fwd")) return e;
   MMI_CHECK_ARG(x && w && y, "mmi_conv_fwd: null pointer");
   MMI_CHECK_ARG(!(bias && stat_partials), "mmi_conv_fwd: bias and BN statistics are mutually exclusive");
+  if (mmi_smallconv_supported(d)) {
+    MMI_CHECK_ARG(d->Cin != 24 || ((uintptr_t)x & 15) == 0, "mmi_conv_fwd: operands must be 16-byte aligned");
+    return mmi_smallconv_fwd(x, w, bias, y, stat_partials, d, (hipStream_t)stream);
+  }
   const bool vec = fwd_vec(d);
   MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mmi_conv_fwd: operands must be 16-byte aligned");
   IgemmP p{};
@@ -729,6 +734,7 @@ extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, f
 extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_dgrad")) return e;
   MMI_CHECK_ARG(dy && w && dx, "mmi_conv_dgrad: null pointer");
+  if (mmi_smallconv_dgrad_supported(d)) return mmi_smallconv_dgrad(dy, w, dx, d, (hipStream_t)stream);
   // A = dy (channels Cout), output columns = Cin
   const bool vec = d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->Cin % 4 == 0;
   MMI_CHECK_ARG(!vec || (((uintptr_t)dy | (uintptr_t)w) & 15) == 0, "mmi_conv_dgrad: operands must be 16-byte aligned");
@@ -783,13 +789,22 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
 extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_wgrad_workspace") != MMI_OK) return 0;
   const WgPlan g = wgrad_plan(d);
-  return g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
+  const size_t generic = g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
+  const size_t small = mmi_smallconv_supported(d) ? mmi_smallconv_wgrad_workspace(d) : 0;
+  return generic > small ? generic : small;
 }
 
 extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
+  if (mmi_smallconv_supported(d) && dbias == nullptr) {
+    if (workspace == nullptr || workspace_bytes < mmi_smallconv_wgrad_workspace(d)) {
+      mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, mmi_smallconv_wgrad_workspace(d));
+      return MMI_ERR_WORKSPACE;
+    }
+    return mmi_smallconv_wgrad(dy, x, dw, workspace, d, (hipStream_t)stream);
+  }
   const WgPlan g = wgrad_plan(d);
   MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
   const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;

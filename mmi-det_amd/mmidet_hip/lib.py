@@ -74,6 +74,9 @@ _SIGS = {
     'mmi_fusion_stats_workspace': (c_size_t, []),
     'mmi_fusion_stats': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),
     'mmi_sgd_ema_step': (c_int, [P, P, c_int, P, P]),
+    'mmi_sobel_add_fwd': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_sobel_add_bwd_workspace': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'mmi_sobel_add_bwd': (c_int, [P, c_int, P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_detect_loss_workspace': (c_size_t, [c_int, c_int64, c_int64]),
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),

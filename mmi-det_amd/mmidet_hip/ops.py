@@ -70,13 +70,14 @@ def _ohwi(w):
     return w
 
 
-OVERLAP_WGRAD = True   # run the weight-gradient GEMM on a side HIP stream next to the data-gradient GEMM
+OVERLAP_WGRAD = __import__("os").environ.get("MMIDET_OVERLAP_WGRAD", "1") != "0"   # weight-gradient GEMM on a side HIP stream next to dgrad
+SHARED_SIDE = __import__("os").environ.get("MMIDET_SHARED_SIDE", "0") == "1"   # one wgrad stream for both backbone lanes
 _side_streams = {}
 
 
 def _side_stream(device):
     """The wgrad companion of the CURRENT stream (each backbone lane has its own)."""
-    key = (device, _stream())
+    key = (device, 0 if SHARED_SIDE else _stream())
     s = _side_streams.get(key)
     if s is None:
         s = torch.cuda.Stream(device=device)
@@ -395,3 +396,38 @@ class _HeadPermute(Function):
 
 def head_permute(x, na):
     return _HeadPermute.apply(x, na)
+
+
+class _SobelAdd(Function):
+    """t = r + EnhanceConv2d(r) for the fixed CEM stencil bank: factor[o]*stencil_{o%8}(sum_c r_c) + bias[o] (+ r)."""
+
+    @staticmethod
+    def forward(ctx, r, factor, bias):
+        r, ldr = rows_of(r)
+        n, h, w, c = r.shape
+        t = torch.empty((n, h, w, c), dtype=r.dtype, device=r.device)
+        chansum = torch.empty((n, h, w), dtype=r.dtype, device=r.device)
+        f = factor.reshape(-1).contiguous()
+        lib.sobel_add_fwd(r.data_ptr(), ldr, f.data_ptr(), bias.data_ptr(), chansum.data_ptr(), t.data_ptr(), c, n, h, w, c,
+                          _stream())
+        ctx.save_for_backward(chansum, f)
+        ctx.cfg = (n, h, w, c, tuple(factor.shape))
+        return t
+
+    @staticmethod
+    def backward(ctx, dt):
+        chansum, f = ctx.saved_tensors
+        n, h, w, c, fshape = ctx.cfg
+        dt, ldd = rows_of(dt)
+        dr = torch.empty((n, h, w, c), dtype=dt.dtype, device=dt.device)
+        df = torch.empty(c, dtype=dt.dtype, device=dt.device)
+        db = torch.empty(c, dtype=dt.dtype, device=dt.device)
+        nbytes = lib.sobel_add_bwd_workspace(n, h, w, c)
+        ws = scratch(nbytes // 4 + 4, dt.device, slot=5)
+        lib.sobel_add_bwd(dt.data_ptr(), ldd, chansum.data_ptr(), f.data_ptr(), dr.data_ptr(), c, df.data_ptr(),
+                          db.data_ptr(), ws.data_ptr(), n, h, w, c, _stream())
+        return dr, df.view(fshape), db
+
+
+def sobel_add(r, factor, bias):
+    return _SobelAdd.apply(r, factor, bias)

@@ -145,10 +145,13 @@ class TrainStep:
         return self._loss, self._items
 
     def _capture(self, imgs_u8, targets):
-        # The twin-lane (RGB/IR on two HIP streams) forward is an eager-mode feature for now: with the extra lane forked
-        # into the capture, hipStreamEndCapture of ROCm 7.2 segfaults on this graph (4000 nodes, ~600 cross-stream
-        # edges).  The wgrad side stream (one fork/join per layer) captures fine.
-        self.model.two_streams = False
+        # Capture keeps ONE level of stream forking.  The twin backbone lanes (RGB/IR on two HIP streams) capture fine and
+        # are worth more (175 vs 184 ms/step) than the per-layer dgrad||wgrad side stream; with both,
+        # hipStreamEndCapture of ROCm 7.2 segfaults (nested forks, ~4000 nodes), so the wgrad overlap is an eager-mode
+        # feature and is switched off for the captured step.
+        from . import ops
+        if self.model.two_streams:
+            ops.OVERLAP_WGRAD = False
         self._imgs, self._targets = imgs_u8.clone(), targets.clone()
         side = torch.cuda.Stream(device=imgs_u8.device)
         side.wait_stream(torch.cuda.current_stream())

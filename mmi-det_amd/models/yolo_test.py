@@ -164,7 +164,8 @@ class Model(nn.Module):
         if lanes:
             ir = self._ir_stream(dev)
             ir.wait_stream(main)
-            x2.record_stream(ir)
+            if not torch.cuda.is_current_stream_capturing():
+                x2.record_stream(ir)
             done = {}
         x = self.Enhance(x)                                        # CEM on the RGB stream only
         y = []
@@ -177,8 +178,9 @@ class Model(nn.Module):
                 for j in self._srcs[m.i]:                          # hand-offs from the other lane
                     if lanes[j] != lanes[m.i]:
                         st_.wait_event(done[j])
-                        for t in _tensors_of(y[j] if y[j] is not None else prev):   # unsaved => j is the previous layer
-                            t.record_stream(st_)
+                        if not torch.cuda.is_current_stream_capturing():   # (a graph's private pool replays fixed addresses)
+                            for t in _tensors_of(y[j] if y[j] is not None else prev):   # unsaved => j is the previous layer
+                                t.record_stream(st_)
                 ctx = torch.cuda.stream(st_)
                 ctx.__enter__()
             if m.f == -4:
