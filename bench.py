@@ -107,9 +107,11 @@ class ConvTimer:
 
         def fl(d):
             return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW
-        wrap('conv_fwd', lambda a: fl(a[5]))
-        wrap('conv_dgrad', lambda a: fl(a[3]))
-        wrap('conv_wgrad', lambda a: fl(a[6]))
+        def desc_of(a):
+            return [x for x in a if hasattr(x, 'Cout')][0]
+        wrap('conv_fwd', lambda a: fl(desc_of(a)))
+        wrap('conv_dgrad', lambda a: fl(desc_of(a)))
+        wrap('conv_wgrad', lambda a: fl(desc_of(a)))
 
     def by_shape(self):
         """[(entry point, shape) -> launches, ms, TFLOP/s] sorted by time: where the GEMM time goes."""

@@ -46,12 +46,25 @@ typedef struct {
 } mmi_conv_desc;
 
 /* y = conv(x, w) [+ bias].  If stat_partials != NULL the epilogue also writes per-row-block column sums of y and y*y
- * (BatchNorm batch statistics, models/common.py:116) to stat_partials[rb][2][Cout], rb < mmi_conv_fwd_row_blocks(). */
+ * (BatchNorm batch statistics, models/common.py:116) to stat_partials[rb][2][Cout], rb < mmi_conv_fwd_row_blocks().
+ *
+ * Workspace (forward and dgrad): shapes whose tile count is a poor multiple of the chip run a stream-K schedule (equal
+ * K-slab shares per resident workgroup, partial tiles folded in K order by the last contributor: deterministic) and need
+ * mmi_conv_{fwd,dgrad}_workspace(d) bytes of device memory, 16-byte aligned; 0 means none (NULL is then fine).  The
+ * buffer must be ZERO-FILLED when first handed over; every launch leaves it ready for the next one, of any shape, as
+ * long as launches sharing a buffer are ordered on one stream. */
 int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
-int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
-                 const mmi_conv_desc* d, void* stream);
+/* Tuning/testing knob of the stream-K planner: 0 = size the grid to the chip (default), n > 0 = n workgroups for every
+ * shape with >= 2 K slabs (lets small test shapes take the schedule), n < 0 = schedule off.  Returns the old value.
+ * Changes what the *_workspace() and row_blocks() queries answer: set it before planning a call, not between. */
+int mmi_set_streamk_slots(int slots);
+size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d);
+int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials, void* workspace,
+                 size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
 /* dx = conv_transpose(dy, w): gradient w.r.t. the input (autograd of the call sites above). dx has row stride ldx. */
-int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, void* stream);
+size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d);
+int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                   const mmi_conv_desc* d, void* stream);
 /* dw (OHWI) = sum over pixels dy^T x; dbias (nullable, Cout floats) = column sums of dy, taken from the same dy tiles
  * (the bias gradient of Detect / Linear costs no extra pass).  workspace holds split-K slabs; query its size first. */
 size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d);

@@ -103,14 +103,43 @@ __device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
   }
 }
 
-template <int V>
+// Streaming kernels: when the grid stride is a multiple of the C/V column groups (FIXED; every power-of-two C of the
+// model), a thread keeps its column group, so the per-channel parameters are loaded once and no 64-bit division runs per
+// element; otherwise the general index arithmetic is used.
+template <int V, bool FIXED>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mi,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo,
                                   int64_t rows, int C, int act) {
   const int cv = C / V;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (FIXED) {
+    const int64_t r0 = e0 / cv, dr = stride / cv;
+    const int c = (int)(e0 - r0 * cv) * V;
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
+    const float* py = y + r0 * ldy + c;
+    const float* pr = res != nullptr ? res + r0 * ldr + c : nullptr;
+    float* po = out + r0 * ldo + c;
+    const int64_t sy = dr * ldy, sr = dr * ldr, so = dr * ldo;
+#pragma unroll 2
+    for (int64_t r = r0; r < rows; r += dr, py += sy, po += so) {
+      const Vec<V> yy = ldv<V>(py);
+      Vec<V> o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) o.v[k] = act_fwd((yy.v[k] - m.v[k]) * is.v[k] * g.v[k] + b.v[k], act);
+      if (pr != nullptr) {
+        const Vec<V> rr = ldv<V>(pr);
+        pr += sr;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] += rr.v[k];
+      }
+      stv<V>(po, o);
+    }
+    return;
+  }
   const int64_t total = rows * cv;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t e = e0; e < total; e += stride) {
     const int64_t r = e / cv;
     const int c = (int)(e - r * cv) * V;
     const Vec<V> yy = ldv<V>(y + r * ldy + c), m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c),
@@ -185,16 +214,42 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   }
 }
 
-template <int V>
+template <int V, bool FIXED>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
                                     const float* __restrict__ mi, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, float* __restrict__ dy, int lddy, int64_t rows, int C,
                                     int act, int frozen) {
   const int cv = C / V;
-  const int64_t total = rows * cv;
   const float inv_rows = 1.0f / (float)rows;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (FIXED) {
+    const int64_t r0 = e0 / cv, dr = stride / cv;
+    const int c = (int)(e0 - r0 * cv) * V;
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
+                 dg = ldv<V>(dgamma + c), db = ldv<V>(dbeta + c);
+    const float* py = y + r0 * ldy + c;
+    const float* pd = dout + r0 * ldd + c;
+    float* po = dy + r0 * lddy + c;
+    const int64_t sy = dr * ldy, sd = dr * ldd, so = dr * lddy;
+#pragma unroll 2
+    for (int64_t r = r0; r < rows; r += dr, py += sy, pd += sd, po += so) {
+      const Vec<V> yy = ldv<V>(py), dd = ldv<V>(pd);
+      Vec<V> o;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (yy.v[k] - m.v[k]) * is.v[k];
+        const float dz = dd.v[k] * act_grad(xh * g.v[k] + b.v[k], act);
+        const float t = frozen ? dz : dz - db.v[k] * inv_rows - xh * dg.v[k] * inv_rows;
+        o.v[k] = g.v[k] * is.v[k] * t;
+      }
+      stv<V>(po, o);
+    }
+    return;
+  }
+  const int64_t total = rows * cv;
+  for (int64_t e = e0; e < total; e += stride) {
     const int64_t r = e / cv;
     const int c = (int)(e - r * cv) * V;
     const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(dout + r * ldd + c), m = ldv<V>(mi + c),
@@ -237,6 +292,13 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int n
 inline int ew_blocks(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+// grid for a streaming kernel over rows x cv column groups; *fixed = the grid stride is a multiple of cv
+inline int ew_grid(int64_t rows, int cv, bool* fixed) {
+  int b = ew_blocks(rows * cv);
+  if (cv > 256 && cv % 256 == 0) b = cdiv(b, cv / 256) * (cv / 256);
+  *fixed = ((int64_t)b * 256) % cv == 0;
+  return b;
 }
 inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
   if (C % 4) return false;
@@ -284,12 +346,17 @@ extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd,
   MMI_CHECK_ARG(y && mean_invstd && gamma && beta && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
   MMI_CHECK_ARG(ldy >= C && ldo >= C && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
   hipStream_t s = (hipStream_t)stream;
-  if (vec_ok(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual, mean_invstd, gamma, beta}))
-    hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, y, ldy, mean_invstd, gamma,
-                       beta, residual, ldr, out, ldo, rows, C, act);
-  else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta,
-                       residual, ldr, out, ldo, rows, C, act);
+  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual, mean_invstd, gamma, beta});
+  bool fixed;
+  const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
+#define LAUNCH_FWD(V_, F_) \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta, residual, \
+                     ldr, out, ldo, rows, C, act)
+  if (vec && fixed) LAUNCH_FWD(4, true);
+  else if (vec) LAUNCH_FWD(4, false);
+  else if (fixed) LAUNCH_FWD(1, true);
+  else LAUNCH_FWD(1, false);
+#undef LAUNCH_FWD
   MMI_CHECK_LAUNCH("mmi_bn_act_fwd");
   return MMI_OK;
 }
@@ -326,12 +393,17 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
-  if (vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta}))
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, y, ldy, dout, ldd,
-                       mean_invstd, gamma, beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd,
-                       gamma, beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen);
+  const bool vec = vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta});
+  bool fixed;
+  const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
+#define LAUNCH_APPLY(V_, F_) \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, \
+                     beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen)
+  if (vec && fixed) LAUNCH_APPLY(4, true);
+  else if (vec) LAUNCH_APPLY(4, false);
+  else if (fixed) LAUNCH_APPLY(1, true);
+  else LAUNCH_APPLY(1, false);
+#undef LAUNCH_APPLY
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply");
   return MMI_OK;
 }

@@ -53,6 +53,8 @@ struct IgemmP {
   const float* zero;  // 16 zero bytes in global memory (source of masked lanes)
   int M, Ncol, Kc, KH, KW, P, Q, Hs, Ws, lda, ldc, stride, pad, Ktot, ldb, mtiles, ntiles;
   int par;  // dgrad of a stride-2 conv: blockIdx.y = output-pixel parity class, which only sees its own taps
+  float* sk_slots;  // stream-K: 2 partial-tile slots of BM*BN floats per workgroup
+  int* sk_count;    // stream-K: per-tile arrival counters (zero before and after every launch)
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -178,7 +180,22 @@ __device__ __forceinline__ f32x4 load_b_kn(const IgemmP& p, const Taps& tp, int 
   return v;
 }
 
-template <int BM, int BN, bool DGRAD, bool VEC>
+// Stream-K schedule (SK): the grid is exactly the number of resident workgroup slots (CUs x occupancy) and every
+// workgroup runs the same number (+-1) of K-slab iterations of the tile-major iteration space [tiles x nk), so a grid of
+// 800 equal tiles no longer costs 4 "layers" of 256 on a chip that holds 768 (measured: 0.335 ms vs 0.262 ms for 768).
+// A workgroup's range is a tail of one tile, whole tiles, and a head of another; partial accumulators go to a workspace
+// slot, a per-tile arrival counter elects the last contributor, which sums the parts in K order (deterministic) and runs
+// the normal epilogue.  Nobody waits on anybody, so residency is a performance assumption, not a correctness one.
+struct SkRange {
+  int q, r;  // every workgroup owns q iterations, the first r own one more
+  __device__ __forceinline__ int start(int b) const { return b * q + (b < r ? b : r); }
+  __device__ __forceinline__ int owner(int x) const {
+    const int edge = r * (q + 1);
+    return x < edge ? x / (q + 1) : r + (x - edge) / q;
+  }
+};
+
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK>
 __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kernel(IgemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / 32;                       // A rows per loader thread
@@ -189,12 +206,13 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
   __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
+  __shared__ int sk_last;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   Taps tp{0, 1, 0, 1, p.KW, p.Ktot};
   int pa = 0, qa = 0, Pc = p.P, Qc = p.Q, Mc = p.M, ntile_tot = p.mtiles * p.ntiles;
-  if (DGRAD && p.par) {  // uniform per workgroup
+  if (!SK && DGRAD && p.par) {  // uniform per workgroup
     pa = blockIdx.y >> 1;
     qa = blockIdx.y & 1;
     Pc = (p.P - pa + 1) >> 1;
@@ -204,206 +222,278 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
     ntile_tot = ((Mc + BM - 1) / BM) * p.ntiles;
     if ((int)blockIdx.x >= ntile_tot) return;
   }
-  const int tile = xcd_remap(blockIdx.x, ntile_tot);
-  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
+  const bool par = !SK && DGRAD && p.par;
+  const int nk = (tp.Ktot + BK - 1) / BK;
+  const int ntaps = tp.Ktot / p.Kc;
   const int kq = (t & 7) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
   const int lrow = t >> 3;     // 0..31
+  const int l31 = lane & 31, lh = lane >> 5;
 
-  RowInfo rows[RA];
-#pragma unroll
-  for (int i = 0; i < RA; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    int orow = -1;
-    if (m < Mc) {
-      const int pq = Pc * Qc;
-      const int img = m / pq, rem = m - img * pq;
-      int pp = rem / Qc, qq = rem - pp * Qc;
-      if (DGRAD && p.par) {
-        pp = 2 * pp + pa;
-        qq = 2 * qq + qa;
-        orow = (img * p.P + pp) * p.Q + qq;
-      }
-      rows[i].base = (int64_t)img * p.Hs * p.Ws;
-      rows[i].ph = DGRAD ? pp + p.pad : pp * p.stride - p.pad;
-      rows[i].qw = DGRAD ? qq + p.pad : qq * p.stride - p.pad;
-    } else {
-      rows[i].base = -1;
-      rows[i].ph = rows[i].qw = 0;
-    }
-    if (DGRAD && p.par && (t & 7) == 0) rowmap[lrow + 32 * i] = orow;  // visible after the K loop's barriers
+  // iteration range of this workgroup: data-parallel = the nk slabs of one tile; stream-K = an even share of everything
+  SkRange sk{0, 0};
+  int bid = 0, it = 0, it_end = nk;
+  if (SK) {
+    bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int total = ntile_tot * nk;
+    sk.q = total / (int)gridDim.x;
+    sk.r = total - sk.q * (int)gridDim.x;
+    it = sk.start(bid);
+    it_end = it + sk.q + (bid < sk.r ? 1 : 0);
   }
+  const int it_begin = it;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  f32x4 ra[RA];
-  constexpr int NB = DGRAD ? KB_IT : RB;
-  f32x4 rb[NB];
-
-  // Vector path: division-free K cursors (advanced by one slab per step) and branch-free loads (an invalid lane reads
-  // the operand's base address and is zeroed by a select), so the loads of the NEXT slab can be issued piecewise
-  // between the MFMA groups of the current one and their address arithmetic runs in the MFMA shadow.
-  const int ntaps = tp.Ktot / p.Kc;
-  KCur ca, cb[NB];
-  int k0cur = 0;
-  if (VEC) {
-    ca.init(kq, p.Kc, tp.ntw);
-    if (DGRAD) {
-#pragma unroll
-      for (int i = 0; i < NB; ++i) cb[i].init(t / VPR + RPI * i, p.Kc, tp.ntw);
-    }
-  }
-  auto load_a_row = [&](int i) {
-    if (!VEC) {
-      ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
-      return;
-    }
-    int64_t pix = 0;
-    const bool ok = (ca.tap < ntaps) & src_pixel<DGRAD>(p, rows[i], tp.kh0 + tp.khs * ca.ti, tp.kw0 + tp.kws * ca.tj, pix);
-    ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
-  };
-  auto load_b_row = [&](int i) {
-    if (!DGRAD) {
-      if (!VEC) {
-        rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0cur + kq);
-        return;
-      }
-      const int n = n0 + lrow + 32 * i, k = k0cur + kq;
-      const bool ok = (n < p.Ncol) & (k < tp.Ktot);
-      rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
+  while (it < it_end) {
+    int tile, ks0, ks1;
+    if (SK) {
+      tile = it / nk;
+      ks0 = it - tile * nk;
+      ks1 = min(nk, ks0 + (it_end - it));
     } else {
-      if (!VEC) {
-        rb[i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
-        return;
-      }
-      const int n = n0 + (t % VPR) * 4;
-      const bool ok = (cb[i].tap < ntaps) & (n < p.Ncol);
-      const int tapw = (tp.kh0 + tp.khs * cb[i].ti) * p.KW + tp.kw0 + tp.kws * cb[i].tj;
-      rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)cb[i].c * p.ldb + (int64_t)tapw * p.Ncol + n : ZERO_SRC);
+      tile = xcd_remap(blockIdx.x, ntile_tot);
+      ks0 = 0;
+      ks1 = nk;
     }
-  };
-  auto advance = [&]() {  // move every cursor to the next slab
-    k0cur += BK;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    RowInfo rows[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + lrow + 32 * i;
+      int orow = -1;
+      if (m < Mc) {
+        const int pq = Pc * Qc;
+        const int img = m / pq, rem = m - img * pq;
+        int pp = rem / Qc, qq = rem - pp * Qc;
+        if (par) {
+          pp = 2 * pp + pa;
+          qq = 2 * qq + qa;
+          orow = (img * p.P + pp) * p.Q + qq;
+        }
+        rows[i].base = (int64_t)img * p.Hs * p.Ws;
+        rows[i].ph = DGRAD ? pp + p.pad : pp * p.stride - p.pad;
+        rows[i].qw = DGRAD ? qq + p.pad : qq * p.stride - p.pad;
+      } else {
+        rows[i].base = -1;
+        rows[i].ph = rows[i].qw = 0;
+      }
+      if (par && (t & 7) == 0) rowmap[lrow + 32 * i] = orow;  // visible after the K loop's barriers
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[RA];
+    constexpr int NB = DGRAD ? KB_IT : RB;
+    f32x4 rb[NB];
+
+    // Vector path: division-free K cursors (advanced by one slab per step) and branch-free loads (an invalid lane reads
+    // the zero source), so the loads of the NEXT slab can be issued piecewise between the MFMA groups of the current one
+    // and their address arithmetic runs in the MFMA shadow.
+    KCur ca, cb[NB];
+    int k0cur = ks0 * BK;
     if (VEC) {
-      ca.advance(p.Kc, tp.ntw);
+      ca.init(k0cur + kq, p.Kc, tp.ntw);
       if (DGRAD) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) cb[i].advance(p.Kc, tp.ntw);
+        for (int i = 0; i < NB; ++i) cb[i].init(k0cur + t / VPR + RPI * i, p.Kc, tp.ntw);
       }
     }
-  };
-  auto gload = [&]() {
+    auto load_a_row = [&](int i) {
+      if (!VEC) {
+        ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
+        return;
+      }
+      int64_t pix = 0;
+      const bool ok = (ca.tap < ntaps) & src_pixel<DGRAD>(p, rows[i], tp.kh0 + tp.khs * ca.ti, tp.kw0 + tp.kws * ca.tj, pix);
+      ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
+    };
+    auto load_b_row = [&](int i) {
+      if (!DGRAD) {
+        if (!VEC) {
+          rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0cur + kq);
+          return;
+        }
+        const int n = n0 + lrow + 32 * i, k = k0cur + kq;
+        const bool ok = (n < p.Ncol) & (k < tp.Ktot);
+        rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
+      } else {
+        if (!VEC) {
+          rb[i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+          return;
+        }
+        const int n = n0 + (t % VPR) * 4;
+        const bool ok = (cb[i].tap < ntaps) & (n < p.Ncol);
+        const int tapw = (tp.kh0 + tp.khs * cb[i].ti) * p.KW + tp.kw0 + tp.kws * cb[i].tj;
+        rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)cb[i].c * p.ldb + (int64_t)tapw * p.Ncol + n : ZERO_SRC);
+      }
+    };
+    auto advance = [&]() {  // move every cursor to the next slab
+      k0cur += BK;
+      if (VEC) {
+        ca.advance(p.Kc, tp.ntw);
+        if (DGRAD) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) load_a_row(i);
+          for (int i = 0; i < NB; ++i) cb[i].advance(p.Kc, tp.ntw);
+        }
+      }
+    };
+    auto gload = [&]() {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) load_b_row(i);
-  };
-  auto lstore = [&](int stage) {
-    float* As = smem + stage * STAGE;
-    float* Bs = As + A_ELEMS;
+      for (int i = 0; i < RA; ++i) load_a_row(i);
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_PAD + kq) = ra[i];
-    if (!DGRAD) {
+      for (int i = 0; i < NB; ++i) load_b_row(i);
+    };
+    auto lstore = [&](int stage) {
+      float* As = smem + stage * STAGE;
+      float* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_PAD + kq) = rb[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[i];
-    }
-  };
-
-  const int nk = (tp.Ktot + BK - 1) / BK;
-  gload();
-  lstore(0);
-  __syncthreads();
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  for (int ks = 0; ks < nk; ++ks) {
-    // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
-    // masked to the zero source, so the last iteration only stages zeros into the idle buffer.
-    advance();
-    const float* As = smem + (MMI_IGEMM_STAGES == 2 ? (ks & 1) : 0) * STAGE;
-    const float* Bs = As + A_ELEMS;
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
-      // 1024 MFMA cycles then cover the tail of the load latency before the LDS stores below)
-#pragma unroll
-      for (int i = 0; i < RA; ++i)
-        if (i % 3 == g) load_a_row(i);
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-        if ((RA + i) % 3 == g) load_b_row(i);
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_PAD + kq) = ra[i];
       if (!DGRAD) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_PAD + kq) = rb[i];
       } else {
 #pragma unroll
+        for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[i];
+      }
+    };
+
+    gload();
+    lstore(0);
+    __syncthreads();
+
+    for (int ks = ks0; ks < ks1; ++ks) {
+      // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
+      // masked to the zero source, so the last iteration only stages zeros (or, in a stream-K segment that stops short
+      // of the tile's end, an unused slab) into the idle buffer.
+      advance();
+      const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
+      const float* Bs = As + A_ELEMS;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
+        // 1024 MFMA cycles then cover the tail of the load latency before the LDS stores below)
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+          if (i % 3 == g) load_a_row(i);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          if ((RA + i) % 3 == g) load_b_row(i);
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+        if (!DGRAD) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + l31) * LDS_PAD + g * 8 + lh * 4);
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[j][e] = Bs[(g * 8 + lh * 4 + e) * BN + wn * WN + j * 32 + l31];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
+      if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
+      lstore(MMI_IGEMM_STAGES == 2 ? ((ks - ks0 + 1) & 1) : 0);
+      __syncthreads();
+    }
+    it += ks1 - ks0;
+
+    if (SK && ks1 - ks0 < nk) {
+      // ---- partial tile: publish, count arrivals, the last contributor folds every part in K order ----
+      // Partials travel with device-scope (sc1) stores and loads: they are coherent across the eight XCD L2s by
+      // themselves, so no agent-scope fence is needed (one would write back and invalidate the whole L2 per segment,
+      // which costs far more than the schedule saves).
+      constexpr int SLOT = BM * BN;
+      float* mine = p.sk_slots + (int64_t)(2 * bid + (it - (ks1 - ks0) != it_begin ? 1 : 0)) * SLOT;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[j][e] = Bs[(g * 8 + lh * 4 + e) * BN + wn * WN + j * 32 + l31];
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 256 + t, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed
+      __syncthreads();
+      const int lo = tile * nk;
+      const int b_first = sk.owner(lo), b_last = sk.owner(lo + nk - 1);
+      if (t == 0) {
+        const int old = __hip_atomic_fetch_add(p.sk_count + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == b_last - b_first;
+        if (last) __hip_atomic_store(p.sk_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+        sk_last = last;
       }
+      __syncthreads();
+      if (!sk_last) continue;  // uniform
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int bb = b_first; bb <= b_last; ++bb) {
+        const float* part = p.sk_slots + (int64_t)(2 * bb + (sk.start(bb) < lo ? 1 : 0)) * SLOT;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += __hip_atomic_load(part + ((i * TN + j) * 16 + r) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
-    if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
-    lstore(MMI_IGEMM_STAGES == 2 ? ((ks + 1) & 1) : 0);
-    __syncthreads();
-  }
 
-  // ---- epilogue: C/D layout of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue: C/D layout of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + l31;
-    const bool cok = col < p.Ncol;
-    const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + l31;
+      const bool cok = col < p.Ncol;
+      const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int row = m0 + lr;
-        const float v = acc[i][j][r] + bv;
-        s1 += v;
-        s2 += v * v;
-        if (cok && row < Mc) p.C[(int64_t)((DGRAD && p.par) ? rowmap[lr] : row) * p.ldc + col] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = m0 + lr;
+          const float v = acc[i][j][r] + bv;
+          s1 += v;
+          s2 += v * v;
+          if (cok && row < Mc) p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
+        }
+      }
+      if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        float* red = smem;  // [2 stats][2 wm][BN]; safe: the K loop ended with a barrier
+        if (lh == 0) {
+          red[(0 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s1;
+          red[(1 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s2;
+        }
       }
     }
-    if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      float* red = smem;  // [2 stats][2 wm][BN]; safe: the K loop ended with a barrier
-      if (lh == 0) {
-        red[(0 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s1;
-        red[(1 * 2 + wm) * BN + wn * WN + j * 32 + l31] = s2;
+    if (p.stat_part != nullptr) {
+      __syncthreads();
+      for (int idx = t; idx < 2 * BN; idx += 256) {
+        const int s = idx / BN, c = idx - s * BN;
+        const int col = n0 + c;
+        if (col < p.Ncol) p.stat_part[((int64_t)mt * 2 + s) * p.Ncol + col] = smem[(s * 2 + 0) * BN + c] + smem[(s * 2 + 1) * BN + c];
       }
-    }
-  }
-  if (p.stat_part != nullptr) {
-    __syncthreads();
-    for (int idx = t; idx < 2 * BN; idx += 256) {
-      const int s = idx / BN, c = idx - s * BN;
-      const int col = n0 + c;
-      if (col < p.Ncol) p.stat_part[((int64_t)mt * 2 + s) * p.Ncol + col] = smem[(s * 2 + 0) * BN + c] + smem[(s * 2 + 1) * BN + c];
+      if (SK) __syncthreads();  // the next segment's prologue overwrites smem
     }
   }
 }
@@ -647,6 +737,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 
 struct FwdPlan {
   int bm, bn, mtiles, ntiles;
+  int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
 FwdPlan plan_tiles(int64_t M, int Ncol) {
   FwdPlan f;
@@ -657,11 +748,81 @@ FwdPlan plan_tiles(int64_t M, int Ncol) {
   if ((int64_t)cdiv(M, 128) * cdiv(Ncol, f.bn) < 512) f.bm = 64, f.bn = 64;
   f.mtiles = cdiv(M, f.bm);
   f.ntiles = cdiv(Ncol, f.bn);
+  f.sk_grid = 0;
   return f;
 }
 
+int g_sk_slots = 0;  // mmi_set_streamk_slots: 0 = chip-sized, > 0 = this many workgroups, < 0 = schedule off
+constexpr int SK_MAX_TILES = 65536;                                  // arrival counters at the head of the workspace
+constexpr size_t SK_COUNTER_BYTES = (size_t)SK_MAX_TILES * sizeof(int);
+
+int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = 256;  // MI355X; also what a GPU-less host plans with
+    (void)hipGetLastError();
+  }
+  return n;
+}
+
+// Resident workgroups per CU of a stream-K kernel variant (registers and LDS decide; 3 by the launch bound).
 template <bool DGRAD>
-int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
+int sk_occupancy(int bn) {
+  static int cache[2] = {0, 0};
+  int& c = cache[bn == 128 ? 1 : 0];
+  if (c == 0) {
+    int n = 0;
+    hipError_t e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true>, 256, 0);
+    c = (e == hipSuccess && n > 0) ? n : 3;
+    (void)hipGetLastError();
+  }
+  return c;
+}
+
+// Stream-K pays when the tile count is a poor multiple of the chip (a kernel's time grows in steps of one workgroup per
+// CU: 769 tiles cost as much as 1024) and K is long enough to amortise the partial-tile traffic.
+template <bool DGRAD>
+FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
+  FwdPlan f = plan_tiles(M, Ncol);
+  if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(Ncol, 64);
+  static const bool off = getenv("MMIDET_NO_STREAMK") != nullptr;
+  const int nk = cdiv(Ktot, BK);
+  if (!vec || !allow_sk || off || g_sk_slots < 0 || nk < (g_sk_slots > 0 ? 2 : 16)) return f;
+  FwdPlan g;
+  g.bm = 128;
+  g.bn = Ncol > 64 ? 128 : 64;
+  g.mtiles = cdiv(M, 128);
+  g.ntiles = cdiv(Ncol, g.bn);
+  const int64_t tiles = (int64_t)g.mtiles * g.ntiles;
+  const int cus = device_cus();
+  const int slots = g_sk_slots > 0 ? g_sk_slots : cus * sk_occupancy<DGRAD>(g.bn);
+  if (tiles > SK_MAX_TILES || tiles * nk < (int64_t)slots || tiles * nk >= (1LL << 31)) return f;
+  if (g_sk_slots == 0) {
+    // measured on the yolov5l shapes: below ~32 slabs per workgroup the partial-tile traffic eats the gain
+    if (tiles * nk < (int64_t)32 * slots) return f;
+    const double layers = (double)tiles / cus, dp_eff = layers / ceil(layers);
+    if (tiles >= slots && dp_eff >= 0.93) {  // one workgroup per tile already fills the chip evenly
+      g.sk_grid = 0;
+      return g;
+    }
+  }
+  g.sk_grid = slots;
+  return g;
+}
+
+size_t sk_workspace_bytes(const FwdPlan& f) {
+  return f.sk_grid > 0 ? SK_COUNTER_BYTES + (size_t)f.sk_grid * 2 * f.bm * f.bn * sizeof(float) : 0;
+}
+
+template <bool DGRAD>
+int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
   IgemmP p = p0;
   p.zero = zero_src();
   if (p.zero == nullptr) {
@@ -670,9 +831,23 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
   }
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
+  if (f.sk_grid > 0) {
+    if (workspace == nullptr || workspace_bytes < sk_workspace_bytes(f) || ((uintptr_t)workspace & 15)) {
+      mmi_set_error("%s: this shape runs the stream-K schedule and needs a 16-byte aligned workspace of %zu bytes (got %zu)",
+                    who, sk_workspace_bytes(f), workspace_bytes);
+      return MMI_ERR_WORKSPACE;
+    }
+    p.sk_count = (int*)workspace;
+    p.sk_slots = (float*)((char*)workspace + SK_COUNTER_BYTES);
+    const dim3 grid(f.sk_grid), block(256);
+    if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true>), grid, block, 0, s, p);
+    MMI_CHECK_LAUNCH(who);
+    return MMI_OK;
+  }
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
-  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_>), grid, block, 0, s, p)
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false>), grid, block, 0, s, p)
   if (!vec) {
     if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
     else LAUNCH(64, 64, false);
@@ -680,7 +855,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, hipStream_t s) {
   else if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, true);
   else LAUNCH(64, 64, true);
 #undef LAUNCH
-  MMI_CHECK_LAUNCH(DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd");
+  MMI_CHECK_LAUNCH(who);
   return MMI_OK;
 }
 
@@ -697,23 +872,46 @@ int check_desc(const mmi_conv_desc* d, const char* who) {
   return MMI_OK;
 }
 
-FwdPlan fwd_plan(const mmi_conv_desc* d, bool vec) {
-  FwdPlan f = plan_tiles((int64_t)d->N * d->Ho * d->Wo, d->Cout);
-  if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(d->Cout, 64);
-  return f;
-}
 bool fwd_vec(const mmi_conv_desc* d) { return d->Cin % 4 == 0 && d->ldx % 4 == 0; }
+FwdPlan fwd_plan(const mmi_conv_desc* d) {
+  return plan_igemm<false>((int64_t)d->N * d->Ho * d->Wo, d->Cout, d->KH * d->KW * d->Cin, fwd_vec(d), true);
+}
+bool dgrad_vec(const mmi_conv_desc* d) { return d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->Cin % 4 == 0; }
+bool dgrad_par(const mmi_conv_desc* d) { return dgrad_vec(d) && d->stride == 2 && d->KH == 3; }
+FwdPlan dgrad_plan(const mmi_conv_desc* d) {
+  // parity mode: the grid is sized for the largest class (ceil(H/2) x ceil(W/2) pixels per image); it keeps the
+  // data-parallel schedule (four K extents in one launch)
+  const bool par = dgrad_par(d);
+  const int64_t mrows = par ? (int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (int64_t)d->N * d->H * d->W;
+  return plan_igemm<true>(mrows, d->Cin, d->KH * d->KW * d->Cout, dgrad_vec(d), !par);
+}
 
 }  // namespace
+
+extern "C" int mmi_set_streamk_slots(int slots) {
+  const int old = g_sk_slots;
+  g_sk_slots = slots;
+  return old;
+}
 
 extern "C" int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_fwd_row_blocks") != MMI_OK) return MMI_ERR_ARG;
   if (mmi_smallconv_supported(d)) return mmi_smallconv_blocks(d);  // CEM layers: direct VALU conv (cem.hip)
-  return fwd_plan(d, fwd_vec(d)).mtiles;
+  return fwd_plan(d).mtiles;
+}
+
+extern "C" size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_fwd_workspace") != MMI_OK || mmi_smallconv_supported(d)) return 0;
+  return sk_workspace_bytes(fwd_plan(d));
+}
+
+extern "C" size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_dgrad_workspace") != MMI_OK || mmi_smallconv_dgrad_supported(d)) return 0;
+  return sk_workspace_bytes(dgrad_plan(d));
 }
 
 extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
-                            const mmi_conv_desc* d, void* stream) {
+                            void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_fwd")) return e;
   MMI_CHECK_ARG(x && w && y, "mmi_conv_fwd: null pointer");
   MMI_CHECK_ARG(!(bias && stat_partials), "mmi_conv_fwd: bias and BN statistics are mutually exclusive");
@@ -728,27 +926,24 @@ extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, f
   p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
-  return launch_igemm<false>(p, fwd_plan(d, vec), vec, (hipStream_t)stream);
+  return launch_igemm<false>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, const mmi_conv_desc* d, void* stream) {
+extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                              const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_dgrad")) return e;
   MMI_CHECK_ARG(dy && w && dx, "mmi_conv_dgrad: null pointer");
   if (mmi_smallconv_dgrad_supported(d)) return mmi_smallconv_dgrad(dy, w, dx, d, (hipStream_t)stream);
   // A = dy (channels Cout), output columns = Cin
-  const bool vec = d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->Cin % 4 == 0;
+  const bool vec = dgrad_vec(d);
   MMI_CHECK_ARG(!vec || (((uintptr_t)dy | (uintptr_t)w) & 15) == 0, "mmi_conv_dgrad: operands must be 16-byte aligned");
   IgemmP p{};
   p.A = dy; p.B = w; p.C = dx; p.bias = nullptr; p.stat_part = nullptr;
   p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
-  p.par = (vec && d->stride == 2 && d->KH == 3) ? 1 : 0;
-  // parity mode: the grid is sized for the largest class (ceil(H/2) x ceil(W/2) pixels per image)
-  const int64_t mrows = p.par ? (int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (int64_t)p.M;
-  FwdPlan f = plan_tiles(mrows, p.Ncol);
-  if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(p.Ncol, 64);
-  return launch_igemm<true>(p, f, vec, (hipStream_t)stream);
+  p.par = dgrad_par(d) ? 1 : 0;
+  return launch_igemm<true>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 namespace {
@@ -766,10 +961,21 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   if (!g.vec) g.bm = g.bn = 64;
   g.mtiles = cdiv(d->Cout, g.bm);
   g.ntiles = cdiv(Ntot, g.bn);
-  const int tiles = g.mtiles * g.ntiles;
+  int tiles = g.mtiles * g.ntiles;
   // Split K (pixels) so that tiles*splits fills whole waves of the 512 resident workgroups (2 per CU): a grid of 1.5
   // waves wastes a quarter of the chip.  Fewer splits win ties (less slab traffic).
-  const int max_splits = (int)((Mpix + 511) / 512);                 // >= 512 pixels (16 K-steps) per split
+  int max_splits = (int)((Mpix + 511) / 512);                       // >= 512 pixels (16 K-steps) per split
+  if (g.vec && (int64_t)tiles * max_splits < 256) {
+    // a launch-bound GEMM (the token projections: 2048 rows x 128..512 channels): 64x64 tiles and K chunks of 128 pixels
+    // put ~10x more workgroups on the chip; the slab traffic is kept below 8 MB
+    g.bm = g.bn = 64;
+    g.mtiles = cdiv(d->Cout, 64);
+    g.ntiles = cdiv(Ntot, 64);
+    tiles = g.mtiles * g.ntiles;
+    max_splits = (int)((Mpix + 127) / 128);
+    const int64_t by_bytes = (int64_t)(8 << 20) / ((int64_t)d->Cout * Ntot * 4 + 1);
+    if (max_splits > by_bytes) max_splits = (int)by_bytes;
+  }
   int cap = tiles > 64 ? 16 : cdiv(1024, tiles);
   if (cap > max_splits) cap = max_splits;
   if (cap < 1) cap = 1;

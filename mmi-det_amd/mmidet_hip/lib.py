@@ -29,8 +29,11 @@ _SIGS = {
     'mmi_version': (c_int, []),
     'mmi_last_error': (c_char_p, []),
     'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
-    'mmi_conv_fwd': (c_int, [P, P, P, P, P, POINTER(ConvDesc), P]),
-    'mmi_conv_dgrad': (c_int, [P, P, P, POINTER(ConvDesc), P]),
+    'mmi_set_streamk_slots': (c_int, [c_int]),
+    'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
+    'mmi_conv_fwd': (c_int, [P, P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
+    'mmi_conv_dgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_wgrad': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
@@ -81,7 +84,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

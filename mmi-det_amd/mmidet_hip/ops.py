@@ -25,6 +25,34 @@ def scratch(nfloats, device, slot=0, stream=None):
     return buf
 
 
+_zeroed = {}
+
+
+def zeroed_scratch(nbytes, device, stream=None):
+    """Grow-only, zero-filled-at-birth byte workspace per (device, stream) for the stream-K convolutions: the kernels keep
+    their arrival counters at zero between launches, so the fill happens once per buffer (include/mmidet_hip.h)."""
+    key = (device, _stream() if stream is None else stream)
+    buf = _zeroed.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _zeroed[key] = buf
+    return buf
+
+
+def conv_fwd(x, w, bias, y, part, d, s):
+    """mmi_conv_fwd on tensors (None -> NULL) with the stream-K workspace the shape asks for."""
+    nb = lib.conv_fwd_workspace(d)
+    ws = zeroed_scratch(nb, x.device, s) if nb else None
+    lib.conv_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                 part.data_ptr() if part is not None else None, ws.data_ptr() if nb else None, nb, d, s)
+
+
+def conv_dgrad(dy, w, dx, d, s):
+    nb = lib.conv_dgrad_workspace(d)
+    ws = zeroed_scratch(nb, dy.device, s) if nb else None
+    lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, d, s)
+
+
 def rows_of(t):
     """Return (tensor, ld): `tensor` is `t` (or a compacted copy) viewed as rows x C with unit channel stride and a
     uniform row stride ld."""
@@ -127,11 +155,11 @@ class _ConvBnAct(Function):
         if training:
             nrb = lib.conv_fwd_row_blocks(d)
             part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows
-            lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), d, s)
+            conv_fwd(x, w, None, y, part, d, s)
             lib.bn_finalize(part.data_ptr(), nrb, rows, cout, eps, momentum, rmean.data_ptr(), rvar.data_ptr(),
                             nbt.data_ptr() if nbt is not None else None, mi.data_ptr(), s)
         else:
-            lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, d, s)
+            conv_fwd(x, w, None, y, None, d, s)
             lib.bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), cout, eps, mi.data_ptr(), s)
         out = torch.empty_like(y)
         if residual is not None:
@@ -167,7 +195,7 @@ class _ConvBnAct(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
-            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
+            conv_dgrad(dy, w, dx, dd, s)
         if both:
             _join_side(x.device)
         return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None
@@ -194,8 +222,7 @@ class _ConvBias(Function):
         d = _desc(xs, cout, k, stride, ldx, cout)
         oshape = (*x.shape[:-1], cout) if w.dim() == 2 else (d.N, d.Ho, d.Wo, cout)
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
-        lib.conv_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), None, d,
-                     _stream())
+        conv_fwd(x, w, bias, y, None, d, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (d, bias is not None)
         return y
@@ -219,7 +246,7 @@ class _ConvBias(Function):
                 dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
-            lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dd, s)
+            conv_dgrad(dy, w, dx, dd, s)
         if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
             db = torch.empty(d.Cout, dtype=x.dtype, device=x.device)

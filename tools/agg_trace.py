@@ -1,0 +1,60 @@
+"""Condense a rocprofv3 --kernel-trace CSV: per (kernel, grid) launch count, total and mean duration, plus the union of
+busy intervals (kernels of the two backbone lanes overlap, so the plain sum over-counts).
+
+usage: python tools/agg_trace.py <..._kernel_trace.csv> [top]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([\w:]+(<[^(]*>)?)', name)
+    s = m.group(1) if m else name
+    return s[:70]
+
+
+def main():
+    path = sys.argv[1]
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    rows = list(csv.DictReader(open(path)))
+    agg = defaultdict(lambda: [0, 0])
+    byname = defaultdict(lambda: [0, 0])
+    iv = []
+    for r in rows:
+        t0, t1 = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        k = short(r['Kernel_Name'])
+        grid = '%sx%sx%s' % (r.get('Grid_Size_X', '?'), r.get('Grid_Size_Y', '?'), r.get('Grid_Size_Z', '?'))
+        a = agg[(k, grid)]
+        a[0] += 1
+        a[1] += t1 - t0
+        b = byname[k]
+        b[0] += 1
+        b[1] += t1 - t0
+        iv.append((t0, t1))
+    iv.sort()
+    busy, cur0, cur1 = 0, None, None
+    for a, b in iv:
+        if cur1 is None or a > cur1:
+            if cur1 is not None:
+                busy += cur1 - cur0
+            cur0, cur1 = a, b
+        else:
+            cur1 = max(cur1, b)
+    if cur1 is not None:
+        busy += cur1 - cur0
+    total = sum(v[1] for v in byname.values())
+    span = iv[-1][1] - iv[0][0] if iv else 0
+    print('launches %d   sum %.2f ms   union-busy %.2f ms   span %.2f ms' % (len(rows), total / 1e6, busy / 1e6, span / 1e6))
+    print('\n== by kernel ==')
+    for k, (n, t) in sorted(byname.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('%-72s x%-6d %9.2f ms  %5.1f%%  %8.1f us' % (k, n, t / 1e6, 100.0 * t / total, t / n / 1e3))
+    print('\n== by kernel and grid ==')
+    for (k, g), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('%-60s %-16s x%-6d %9.2f ms  %8.1f us' % (k[:60], g, n, t / 1e6, t / n / 1e3))
+
+
+if __name__ == '__main__':
+    main()

@@ -12,6 +12,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, s
     (16, 320, 320, 64, 128, 3, 2), (16, 160, 160, 128, 256, 3, 2), (16, 80, 80, 256, 512, 3, 2), (16, 40, 40, 512, 1024, 3, 2),
     (16, 160, 160, 128, 64, 1, 1), (16, 80, 80, 256, 128, 1, 1), (16, 40, 40, 512, 256, 1, 1), (16, 20, 20, 1024, 512, 1, 1),
     (16, 20, 20, 2048, 1024, 1, 1), (16, 320, 320, 12, 64, 3, 1), (2048, 1, 1, 1024, 4096, 1, 1), (2048, 1, 1, 4096, 1024, 1, 1),
+    (16, 160, 160, 64, 64, 1, 1), (16, 80, 80, 128, 128, 1, 1), (16, 40, 40, 256, 256, 1, 1), (16, 20, 20, 512, 512, 1, 1),
+    (2048, 1, 1, 128, 128, 1, 1), (2048, 1, 1, 256, 256, 1, 1), (2048, 1, 1, 512, 512, 1, 1), (2048, 1, 1, 1024, 1024, 1, 1),
 ]
 
 
@@ -43,8 +45,8 @@ def main():
         ws = torch.empty(max(nb // 4, 1), device=d)
         part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co, device=d)
         fl = 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k
-        t1 = timeit(lambda: lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), desc, st))
-        t2 = timeit(lambda: lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), desc, st))
+        t1 = timeit(lambda: ops.conv_fwd(x, w, None, y, part, desc, st))
+        t2 = timeit(lambda: ops.conv_dgrad(dy, w, dx, desc, st))
         t3 = timeit(lambda: lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st))
         print('%-34s %9.1f %9.1f %9.1f   (%.3f %.3f %.3f)' % (str((B, H, W, Ci, Co, k, s)), fl / t1 / 1e9, fl / t2 / 1e9,
                                                                 fl / t3 / 1e9, t1, t2, t3), flush=True)

@@ -21,8 +21,8 @@ nb = lib.conv_wgrad_workspace(desc)
 ws = torch.empty(max(nb // 4, 1), device=d)
 part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Co, device=d)
 for _ in range(3):
-    lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), desc, st)
-    lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), desc, st)
+    ops.conv_fwd(x, w, None, y, part, desc, st)
+    ops.conv_dgrad(dy, w, dx, desc, st)
     lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
 torch.cuda.synchronize()
 print('flop per launch', 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k)
