@@ -511,13 +511,17 @@ struct WgradP {
   int64_t slab_stride;
 };
 
+// LDS stages of the wgrad kernel: single-buffered (3+ workgroups per CU, +3..10 % measured on the 3x3 layers) except for
+// the 64x64 tile of the tall-skinny 1x1 layers, whose short MFMA phase cannot hide a second barrier per slab.
+#define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
+
 template <int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
   constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN, STAGE = A_ELEMS + B_ELEMS;
-  __shared__ __align__(16) float smem[2 * STAGE];
+  __shared__ __align__(16) float smem[MMI_WGRAD_STAGES * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
-    const float* As = smem + (ks & 1) * STAGE;
+    const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {  // groups of four k-steps: all fragment reads up front, then 4*TM*TN MFMAs
@@ -677,7 +681,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    lstore((ks + 1) & 1);
+    if (MMI_WGRAD_STAGES == 1) __syncthreads();
+    lstore(MMI_WGRAD_STAGES == 2 ? ((ks + 1) & 1) : 0);
     __syncthreads();
   }
 
@@ -951,6 +956,28 @@ struct WgPlan {
   int bm, bn, mtiles, ntiles, splits, chunk;
   bool vec;
 };
+// resident workgroups of a wgrad variant on the whole chip (registers / LDS decide: 3 per CU for 128x128, 8 for 64x64)
+int wgrad_slots(int bm, int bn, bool vec) {
+  static int cache[5] = {0, 0, 0, 0, 0};
+  const int idx = !vec ? 0 : (bm == 128 ? (bn == 128 ? 1 : 2) : (bn == 128 ? 3 : 4));
+  if (cache[idx] == 0) {
+    int n = 0;
+    hipError_t e;
+    switch (idx) {
+      case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<64, 64, false>, 256, 0); break;
+      case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<128, 128, true>, 256, 0); break;
+      case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<128, 64, true>, 256, 0); break;
+      case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<64, 128, true>, 256, 0); break;
+      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<64, 64, true>, 256, 0); break;
+    }
+    static const int guess[5] = {5, 3, 5, 5, 8};
+    cache[idx] = (e == hipSuccess && n > 0) ? n : guess[idx];
+    if (idx == 0 || idx == 4) cache[idx] = 2;  // 64x64: long K chunks stream better than many short ones (measured)
+    (void)hipGetLastError();
+  }
+  return cache[idx] * device_cus();
+}
+
 WgPlan wgrad_plan(const mmi_conv_desc* d) {
   WgPlan g;
   const int Ntot = d->KH * d->KW * d->Cin;
@@ -962,8 +989,8 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   g.mtiles = cdiv(d->Cout, g.bm);
   g.ntiles = cdiv(Ntot, g.bn);
   int tiles = g.mtiles * g.ntiles;
-  // Split K (pixels) so that tiles*splits fills whole waves of the 512 resident workgroups (2 per CU): a grid of 1.5
-  // waves wastes a quarter of the chip.  Fewer splits win ties (less slab traffic).
+  // Split K (pixels) so that tiles*splits fills whole waves of the resident workgroups of the variant (wgrad_slots): a grid of 1.5 waves
+  // wastes a quarter of the chip.  Fewer splits win ties (less slab traffic).
   int max_splits = (int)((Mpix + 511) / 512);                       // >= 512 pixels (16 K-steps) per split
   if (g.vec && (int64_t)tiles * max_splits < 256) {
     // a launch-bound GEMM (the token projections: 2048 rows x 128..512 channels): 64x64 tiles and K chunks of 128 pixels
@@ -976,14 +1003,15 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
     const int64_t by_bytes = (int64_t)(8 << 20) / ((int64_t)d->Cout * Ntot * 4 + 1);
     if (max_splits > by_bytes) max_splits = (int)by_bytes;
   }
-  int cap = tiles > 64 ? 16 : cdiv(1024, tiles);
+  const int slots = wgrad_slots(g.bm, g.bn, g.vec);
+  int cap = tiles > 64 ? 16 : cdiv(2 * slots, tiles);
   if (cap > max_splits) cap = max_splits;
   if (cap < 1) cap = 1;
   int splits = 1;
   double best = 0.0;
   for (int sp = 1; sp <= cap; ++sp) {
     const int blocks = tiles * sp;
-    const double eff = (double)blocks / (double)(cdiv(blocks, 512) * 512);
+    const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots);
     if (eff > best + 1e-9) best = eff, splits = sp;
   }
   g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;
