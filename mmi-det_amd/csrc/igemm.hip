@@ -525,10 +525,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so the (tile, split) pairs are renumbered to put
+  // all tiles of one pixel chunk on one XCD back to back: they read the same dy / x rows, which then come out of that
+  // XCD's L2 instead of crossing the fabric once per tile (PMC: 885 MB fetched per 3x3 128->128 launch before, 105 MB
+  // algorithmic).
+  const int ntile_tot = p.mtiles * p.ntiles;
+  const int wg = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int split = wg / ntile_tot, tile = wg - split * ntile_tot;
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int kbeg = blockIdx.y * p.chunk;
+  const int kbeg = split * p.chunk;
   const int kend = min(kbeg + p.chunk, p.Mpix);
 
   // A loader: float4 along co
@@ -694,10 +700,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < RPA; ++i) s += red[i * BM + t];
-      p.OUTB[(int64_t)blockIdx.y * p.slab_stride + m0 + t] = s;
+      p.OUTB[(int64_t)split * p.slab_stride + m0 + t] = s;
     }
   }
-  float* out = p.OUT + (int64_t)blockIdx.y * p.slab_stride;
+  float* out = p.OUT + (int64_t)split * p.slab_stride;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + l31;

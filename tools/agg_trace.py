@@ -1,7 +1,8 @@
 """Condense a rocprofv3 --kernel-trace CSV: per (kernel, grid) launch count, total and mean duration, plus the union of
 busy intervals (kernels of the two backbone lanes overlap, so the plain sum over-counts).
 
-usage: python tools/agg_trace.py <..._kernel_trace.csv> [top]"""
+usage: python tools/agg_trace.py <..._kernel_trace.csv> [top] [tail_ms]
+(tail_ms: only the kernels that start in the last tail_ms of the trace, e.g. the graph-replayed timed steps)"""
 import csv
 import re
 import sys
@@ -20,6 +21,10 @@ def main():
     path = sys.argv[1]
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     rows = list(csv.DictReader(open(path)))
+    if len(sys.argv) > 3:
+        end = max(int(r['End_Timestamp']) for r in rows)
+        cut = end - float(sys.argv[3]) * 1e6
+        rows = [r for r in rows if int(r['Start_Timestamp']) >= cut]
     agg = defaultdict(lambda: [0, 0])
     byname = defaultdict(lambda: [0, 0])
     iv = []
