@@ -219,10 +219,16 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-gemm', default=None, help='write the per-shape GEMM time table of the roofline pass here')
+    ap.add_argument('--ddp', action='store_true', help='run the data-parallel code path even on one GPU (world size 1)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
 
     t_start = time.perf_counter()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 from native code, so the real stdout
+    # is parked on a private descriptor and fd 1 points at stderr until the result is written.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -230,9 +236,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the product path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    ddp = world > 1 or args.ddp
+    if ddp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from mmidet_hip.train_step import TrainStep
@@ -246,11 +254,12 @@ def main():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = args.dropout
     model.train()
-    # Whole-step hipGraph on one GPU (the eager step is host-bound: ~175 ms of launch enqueueing per step); the
-    # multi-GPU path stays eager so that the RCCL collectives are issued by the grad-ready hooks as backward runs.
-    use_graph = (world == 1) and not args.no_graph
+    # hipGraph replay (the eager step is host-bound: ~135 ms of launch enqueueing per step).  One GPU: the whole step is
+    # one graph.  Data parallel: forward+backward is the graph, then the bucket all-reduces (RCCL) and the one-launch
+    # optimizer follow on the same stream (--no-graph: eager, collectives issued by grad-ready hooks during backward).
+    use_graph = not args.no_graph
     ts = TrainStep(model, nc, 640, bs, world_size=world, accumulate=1, graph=use_graph)
-    if world > 1:
+    if ddp:
         from mmidet_hip.ddp import GradReducer
         red = GradReducer(list(model.parameters()))
         red.broadcast_parameters(model)
@@ -262,7 +271,7 @@ def main():
         timer.install()          # inert until timer.start(); events cannot be recorded inside a graph replay
 
     def barrier():
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -317,7 +326,8 @@ def main():
                                     's_add': 'yolov5s fusion_add (fusion modules off), nc=9'}[args.workload],
                        'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,640,640)', 'dropout_p': args.dropout,
                        'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
-                       'launch_mode': 'whole-step hipGraph replay' if use_graph else 'eager',
+                       'launch_mode': ('eager' if not use_graph else 'whole-step hipGraph replay' if not ddp else
+                                       'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
                        'loss': [round(float(v), 5) for v in items.tolist()]},
         }
@@ -340,8 +350,9 @@ def main():
                                'step_algorithmic_TFLOP/s': round(3 * WORKLOADS[args.workload][6] * 1e9 * value / 1e12, 2)}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.workload)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
+    if ddp:
         dist.destroy_process_group()
 
 

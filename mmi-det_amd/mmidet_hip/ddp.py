@@ -42,6 +42,7 @@ class GradReducer:
             for p in b.params:
                 self._of[p] = b
                 p.register_post_accumulate_grad_hook(self._ready)
+        self.enabled = True      # False while a hipGraph of forward+backward is captured/replayed: see reduce_now()
         self.cuda = params[0].is_cuda
         self.comm = torch.cuda.Stream(device=params[0].device) if self.cuda else None
         self.avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else dist.ReduceOp.SUM
@@ -78,6 +79,8 @@ class GradReducer:
             b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
 
     def _ready(self, p):
+        if not self.enabled:
+            return
         b = self._of[p]
         b.pending -= 1
         if b.pending == 0 and not b.launched:
@@ -90,6 +93,14 @@ class GradReducer:
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
+            if self.avg == dist.ReduceOp.SUM:
+                b.flat.div_(self.world)
+
+    def reduce_now(self):
+        """All buckets on the current stream, after a replayed forward+backward graph (hooks cannot fire inside a replay).
+        Not overlapped with backward: 832 MB over xGMI is a few ms against a 150 ms step, and the replay saves far more."""
+        for b in self.buckets:
+            dist.all_reduce(b.flat, op=self.avg, group=self.pg)
             if self.avg == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
 

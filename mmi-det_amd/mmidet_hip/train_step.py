@@ -89,7 +89,7 @@ class TrainStep:
         assert not (graph and not fused_optimizer), 'graph mode needs the fused optimizer (device-resident hyper-parameters)'
 
     # ---- the step body (eager; also what gets captured) ----------------------------------------------------------------
-    def _body(self, imgs_u8, targets):
+    def _body(self, imgs_u8, targets, reduce=True):
         model = self.model
         F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
         imgs = imgs_u8.float() / 255.0                                                  # train.py:743
@@ -98,10 +98,11 @@ class TrainStep:
         loss, items = self.compute_loss(pred, targets, comb.reshape(-1))                # train.py:789 (+ B2 reshape)
         if self.world_size > 1:
             loss = loss * self.world_size                                               # train.py:790-791
-        if self.reducer is not None:
+        reduce = reduce and self.reducer is not None
+        if reduce:
             self.reducer.prepare()
         loss.sum().backward()                                                           # train.py:796
-        if self.reducer is not None:
+        if reduce:
             self.reducer.finish()                                                       # mean over ranks, as DDP
         return loss, items
 
@@ -124,6 +125,8 @@ class TrainStep:
     def step(self, imgs_u8, targets):
         if self.use_graph:
             return self._graph_step(imgs_u8, targets)
+        if self.reducer is not None:
+            self.reducer.enabled = True          # (a captured step had switched the grad-ready hooks off)
         loss, items = self._body(imgs_u8, targets)
         self.ni += 1
         if self.ni % self.accumulate == 0:
@@ -141,6 +144,11 @@ class TrainStep:
         self._targets.copy_(targets, non_blocking=True)
         self.optimizer.upload_hyper()
         self._graph.replay()
+        if self.reducer is not None:
+            # data parallel: the graph holds forward+backward only (gradients land in the reducer's flat buckets); the
+            # collectives and the one-launch optimizer follow on the same stream
+            self.reducer.reduce_now()
+            self._update(in_capture=True)
         self.ni += 1
         return self._loss, self._items
 
@@ -162,6 +170,12 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._loss, self._items = self._body(self._imgs, self._targets)
-            self._update(in_capture=True)
+        if self.reducer is not None:
+            self.reducer.enabled = False                   # no collectives inside the capture: see _graph_step
+        # data parallel: RCCL's watchdog thread polls events of finished collectives; under the default (global) capture
+        # error mode that query aborts the process while this thread is capturing
+        mode = 'thread_local' if self.reducer is not None else 'global'
+        with torch.cuda.graph(self._graph, capture_error_mode=mode):
+            self._loss, self._items = self._body(self._imgs, self._targets, reduce=False)
+            if self.reducer is None:
+                self._update(in_capture=True)

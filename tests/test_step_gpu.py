@@ -152,3 +152,29 @@ def test_padded_targets_are_ignored():
     for i in range(3):
         assert torch.equal(a[0][i], b[0][i]) and torch.equal(a[1][i], b[1][i])
         assert all(torch.equal(u, v) for u, v in zip(a[2][i], b[2][i]))
+
+
+def test_data_parallel_graph_step_matches_whole_step_graph():
+    """The N>1 launch structure on one GPU (world size 1, RCCL): forward+backward replayed as a graph, then bucket
+    all-reduce and the fused optimizer eagerly -- same losses and weights as the single-GPU whole-step graph."""
+    import os
+    import torch.distributed as dist
+    from mmidet_hip.ddp import GradReducer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+    try:
+        m1, ts1, cfg = make(graph=True)
+        m2, ts2, _ = make(graph=True)
+        ts2.reducer = GradReducer(list(m2.parameters()))
+        batches = [batch(cfg, 30 + i) for i in range(3)]
+        for imgs, tg in batches:
+            l1, i1 = ts1.step(imgs, tg)
+            l2, i2 = ts2.step(imgs, tg)
+            close(l1, l2, what='loss', tol=2e-3)
+            close(i1, i2, what='items', tol=2e-3)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=2e-3)
+        close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=2e-3)
+        assert all(float(b.flat.abs().max()) == 0.0 for b in ts2.reducer.buckets), 'buckets are zeroed after the update'
+    finally:
+        dist.destroy_process_group()
