@@ -118,6 +118,9 @@ int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, fl
 int mmi_nchw_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int N, int C, int H,
                      int W, void* stream);
 int mmi_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, void* stream);
+/* Input wire format (utils/datasets.py:1565: uint8 (N,6,H,W), RGB = channels 0-2, IR = 3-5) -> the two fp32 NHWC
+ * images x/255 that train.py:743-745 computes with .float()/255 and two channel slices. */
+int mmi_u8_pair_to_nhwc(const uint8_t* in, float* rgb, float* ir, int N, int H, int W, void* stream);
 /* Focus space-to-depth (models/common.py:708): in (N,H,W,C) -> out (N,H/2,W/2,4C), channel = q*C+c,
  * q: (dy,dx)=(0,0),(1,0),(0,1),(1,1).  inverse=1: in is a (N,H/2,W/2,4C) gradient, out the (N,H,W,C) gradient. */
 int mmi_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream);

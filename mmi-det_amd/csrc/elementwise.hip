@@ -228,7 +228,34 @@ inline bool vec4(int C, std::initializer_list<int> lds, std::initializer_list<co
   return true;
 }
 
+// uint8 (N, 2*C3, H, W) loader batch -> two fp32 NHWC images x/255 (train.py:743-745 in one pass: the reference makes
+// a float copy, divides, and hands out two strided channel slices that the first layers then re-layout)
+__global__ void u8_pair_to_nhwc_kernel(const uint8_t* __restrict__ in, float* __restrict__ a, float* __restrict__ b, int N,
+                                       int H, int W) {
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / hw, pix = i - n * hw;
+    const uint8_t* src = in + n * 6 * hw + pix;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = (float)src[c * hw] / 255.0f;  // a true division, as `imgs.float() / 255.0`
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a[i * 3 + c] = v[c];
+      b[i * 3 + c] = v[3 + c];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mmi_u8_pair_to_nhwc(const uint8_t* in, float* rgb, float* ir, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(in && rgb && ir && N > 0 && H > 0 && W > 0, "mmi_u8_pair_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(u8_pair_to_nhwc_kernel, dim3(ew_blocks((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, in,
+                     rgb, ir, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_u8_pair_to_nhwc");
+  return MMI_OK;
+}
 
 extern "C" int mmi_nchw_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* y, int N, int C,
                                 int H, int W, void* stream) {

@@ -45,6 +45,7 @@ _SIGS = {
                                      c_int, P]),
     'mmi_colsum': (c_int, [P, c_int, c_int64, c_int, P, P, P]),
     'mmi_nchw_to_nhwc': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_u8_pair_to_nhwc': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'mmi_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_space_to_depth': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_head_permute': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -366,8 +366,24 @@ def spp_pool(x):
     return _SppPool.apply(x)
 
 
+def u8_pair_to_nhwc(imgs_u8):
+    """Loader batch uint8 (N,6,H,W) -> (rgb, ir) fp32 NHWC in [0,1], marked so that Model.forward skips its own
+    NCHW->NHWC pass (train.py:743-745 fused; bit-identical to `.float() / 255` + slice + re-layout)."""
+    assert imgs_u8.dtype == torch.uint8 and imgs_u8.dim() == 4 and imgs_u8.shape[1] == 6 and imgs_u8.is_cuda
+    x = imgs_u8.contiguous()
+    n, _, h, w = x.shape
+    rgb = torch.empty((n, h, w, 3), dtype=torch.float32, device=x.device)
+    ir = torch.empty_like(rgb)
+    lib.u8_pair_to_nhwc(x.data_ptr(), rgb.data_ptr(), ir.data_ptr(), n, h, w, _stream())
+    rgb.mmi_nhwc = ir.mmi_nhwc = True
+    return rgb, ir
+
+
 def nchw_to_nhwc(x):
-    """Boundary op (no gradient: the model inputs are images).  Accepts strided NCHW views (train.py:744-745)."""
+    """Boundary op (no gradient: the model inputs are images).  Accepts strided NCHW views (train.py:744-745); tensors
+    that u8_pair_to_nhwc produced are NHWC already."""
+    if getattr(x, 'mmi_nhwc', False):
+        return x
     assert x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda
     n, c, h, w = x.shape
     y = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)

@@ -22,6 +22,7 @@ from utils.loss import ComputeLoss
 from utils.torch_utils import ModelEMA
 
 from . import fusion_ops as F2
+from . import ops
 from .optim import FusedSGDEMA
 
 HYP_SCRATCH = dict(lr0=0.01, lrf=0.2, momentum=0.937, weight_decay=0.0005, warmup_epochs=3.0, warmup_momentum=0.8,
@@ -92,8 +93,11 @@ class TrainStep:
     def _body(self, imgs_u8, targets, reduce=True):
         model = self.model
         F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
-        imgs = imgs_u8.float() / 255.0                                                  # train.py:743
-        rgb, ir = imgs[:, :3], imgs[:, 3:]                                              # train.py:744-745 (strided views)
+        if imgs_u8.dtype == torch.uint8:
+            rgb, ir = ops.u8_pair_to_nhwc(imgs_u8)                                      # train.py:743-745 in one kernel
+        else:
+            imgs = imgs_u8.float() / 255.0                                              # train.py:743
+            rgb, ir = imgs[:, :3], imgs[:, 3:]                                          # train.py:744-745 (strided views)
         pred, comb = model(rgb, ir)                                                     # train.py:788
         loss, items = self.compute_loss(pred, targets, comb.reshape(-1))                # train.py:789 (+ B2 reshape)
         if self.world_size > 1:
@@ -157,7 +161,6 @@ class TrainStep:
         # are worth more (175 vs 184 ms/step) than the per-layer dgrad||wgrad side stream; with both,
         # hipStreamEndCapture of ROCm 7.2 segfaults (nested forks, ~4000 nodes), so the wgrad overlap is an eager-mode
         # feature and is switched off for the captured step.
-        from . import ops
         if self.model.two_streams:
             ops.OVERLAP_WGRAD = False
         self._imgs, self._targets = imgs_u8.clone(), targets.clone()

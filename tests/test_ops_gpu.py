@@ -193,6 +193,13 @@ def test_elementwise_layout_ops():
     for sl in (slice(0, 3), slice(3, 6)):
         y = ops.nchw_to_nhwc(x6[:, sl])
         assert torch.equal(y.cpu(), nhwc(imgs[:, sl]))
+    # the loader's uint8 (B,6,H,W) batch -> both fp32 NHWC images in one pass: bit-equal to .float()/255 + slices
+    u8 = torch.randint(0, 256, (3, 6, 20, 36), dtype=torch.uint8, generator=g)
+    u8[0, :, 0, :6] = torch.tensor([0, 1, 127, 128, 254, 255], dtype=torch.uint8)
+    rgb, ir = ops.u8_pair_to_nhwc(u8.to(d))
+    ref6 = u8.float() / 255.0
+    assert torch.equal(rgb.cpu(), nhwc(ref6[:, :3])) and torch.equal(ir.cpu(), nhwc(ref6[:, 3:]))
+    assert ops.nchw_to_nhwc(rgb) is rgb        # already in the kernels' layout: Model.forward does not convert again
     # Focus space-to-depth (common.py:708)
     x = torch.randn(2, 3, 16, 24, generator=g, requires_grad=True)
     ref = torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1)
