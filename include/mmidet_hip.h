@@ -61,6 +61,11 @@ int mmi_set_streamk_slots(int slots);
 size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d);
 int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials, void* workspace,
                  size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+/* Inference form of Conv after Model.fuse() (models/common.py:124-125 fuseforward, utils/torch_utils.py:181-201):
+ * y = act(conv(x, w) + bias) [+ residual]; act is an MMI_ACT_* code, residual (row stride ldr) may be NULL.  Same
+ * workspace rule as mmi_conv_fwd. */
+int mmi_conv_bias_act_fwd(const float* x, const float* w, const float* bias, const float* residual, int ldr, int act,
+                          float* y, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
 /* dx = conv_transpose(dy, w): gradient w.r.t. the input (autograd of the call sites above). dx has row stride ldx. */
 size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d);
 int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
@@ -228,6 +233,21 @@ int mmi_detect_loss(const float* const* preds, float* const* dpreds, const int32
  * launch can live in a captured graph while the schedule changes). */
 #define MMI_OPT_CHUNK 65536
 int mmi_sgd_ema_step(const void* recs_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, void* stream);
+
+/* ---- evaluation path ------------------------------------------------------------------------
+ * Detect in eval mode (models/yolo_test.py:57-66): x is one level's permuted head output (B,na,ny,nx,no); writes the
+ * decoded rows [sigmoid -> (xy*2-0.5+grid)*stride, (wh*2)^2*anchor, conf...] into z (B,total_rows,no) at row_offset
+ * (levels are concatenated along rows, yolo_test.py:68).  anchor_px: the level's na x 2 anchors in pixels (anchor_grid). */
+int mmi_detect_decode(const float* x, float* z, int B, int na, int ny, int nx, int no, int64_t total_rows,
+                      int64_t row_offset, float stride, const float* anchor_px, void* stream);
+/* non_max_suppression (utils/general.py:486-580; NMS proper = torchvision.ops.nms semantics): pred (B,R,nc+5) decoded
+ * rows; class_mask bit j = class j allowed (general.py:549-550 `classes`; all ones = no filter); max_wh 4096 is the
+ * reference's class offset; out (B,max_det,6) = [x1,y1,x2,y2,conf,cls] by decreasing confidence, nout[B] rows valid.
+ * Every candidate takes part (the reference first cuts to its 30 000 best). */
+size_t mmi_nms_workspace(int B, int64_t R, int nc, int multi_label);
+int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float iou_thres, uint64_t class_mask, int agnostic,
+            int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes, float* out, int* nout,
+            void* stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,8 @@ struct IgemmP {
   const float* zero;  // 16 zero bytes in global memory (source of masked lanes)
   int M, Ncol, Kc, KH, KW, P, Q, Hs, Ws, lda, ldc, stride, pad, Ktot, ldb, mtiles, ntiles;
   int par;  // dgrad of a stride-2 conv: blockIdx.y = output-pixel parity class, which only sees its own taps
+  const float* res;  // inference epilogue (Model.fuse()): y = act(acc + bias) + res[row * ldr + col]; null = no residual
+  int ldr, act;
   float* sk_slots;  // stream-K: 2 partial-tile slots of BM*BN floats per workgroup
   int* sk_count;    // stream-K: per-tile arrival counters (zero before and after every launch)
 };
@@ -470,9 +472,11 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
         for (int r = 0; r < 16; ++r) {
           const int lr = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int row = m0 + lr;
-          const float v = acc[i][j][r] + bv;
+          float v = acc[i][j][r] + bv;
           s1 += v;
           s2 += v * v;
+          if (!DGRAD && p.act != MMI_ACT_NONE) v = act_fwd(v, p.act);  // uniform; training never sets it (BN follows)
+          if (!DGRAD && p.res != nullptr && cok && row < Mc) v += p.res[(int64_t)row * p.ldr + col];
           if (cok && row < Mc) p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
         }
       }
@@ -921,23 +925,43 @@ extern "C" size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d) {
   return sk_workspace_bytes(dgrad_plan(d));
 }
 
-extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
-                            void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
-  if (int e = check_desc(d, "mmi_conv_fwd")) return e;
-  MMI_CHECK_ARG(x && w && y, "mmi_conv_fwd: null pointer");
-  MMI_CHECK_ARG(!(bias && stat_partials), "mmi_conv_fwd: bias and BN statistics are mutually exclusive");
-  if (mmi_smallconv_supported(d)) {
-    MMI_CHECK_ARG(d->Cin != 24 || ((uintptr_t)x & 15) == 0, "mmi_conv_fwd: operands must be 16-byte aligned");
+namespace {
+int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, int ldr, int act, float* y,
+                  float* stat_partials, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream,
+                  const char* who) {
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(x && w && y, "%s: null pointer", who);
+  MMI_CHECK_ARG(!(bias && stat_partials), "%s: bias and BN statistics are mutually exclusive", who);
+  const bool plain = residual == nullptr && act == MMI_ACT_NONE;
+  if (mmi_smallconv_supported(d) && plain) {
+    MMI_CHECK_ARG(d->Cin != 24 || ((uintptr_t)x & 15) == 0, "%s: operands must be 16-byte aligned", who);
     return mmi_smallconv_fwd(x, w, bias, y, stat_partials, d, (hipStream_t)stream);
   }
   const bool vec = fwd_vec(d);
-  MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mmi_conv_fwd: operands must be 16-byte aligned");
+  MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "%s: operands must be 16-byte aligned", who);
   IgemmP p{};
   p.A = x; p.B = w; p.C = y; p.bias = bias; p.stat_part = stat_partials;
+  p.res = residual; p.ldr = ldr; p.act = act;
   p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
   return launch_igemm<false>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
+                            void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  return conv_fwd_impl(x, w, bias, nullptr, 0, MMI_ACT_NONE, y, stat_partials, workspace, workspace_bytes, d, stream,
+                       "mmi_conv_fwd");
+}
+
+extern "C" int mmi_conv_bias_act_fwd(const float* x, const float* w, const float* bias, const float* residual, int ldr,
+                                     int act, float* y, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                                     void* stream) {
+  MMI_CHECK_ARG(act == MMI_ACT_NONE || act == MMI_ACT_SILU || act == MMI_ACT_LEAKY, "mmi_conv_bias_act_fwd: unknown activation %d", act);
+  MMI_CHECK_ARG(residual == nullptr || (d && ldr >= d->Cout), "mmi_conv_bias_act_fwd: residual row stride < Cout");
+  return conv_fwd_impl(x, w, bias, residual, ldr, act, y, nullptr, workspace, workspace_bytes, d, stream,
+                       "mmi_conv_bias_act_fwd");
 }
 
 extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,

@@ -261,6 +261,57 @@ def conv_bias(x, w, bias=None, stride=1):
     return _ConvBias.apply(x, w, bias, stride)
 
 
+def conv_bias_act(x, w, bias, stride=1, act=ACT_SILU, residual=None):
+    """Inference form of Conv after Model.fuse() (models/common.py:124-125): act(conv(x, w) + bias) [+ residual] in one
+    kernel.  No autograd (the reference's fused conv is requires_grad_(False) as well)."""
+    assert not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)), \
+        'fused Conv+BN layers are inference-only (utils/torch_utils.py:189)'
+    x, ldx = rows_of(x)
+    w = _ohwi(w)
+    cout, k = w.shape[0], w.shape[2]
+    d = _desc(x.shape, cout, k, stride, ldx, cout)
+    y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = rows_of(residual)
+    s = _stream()
+    nb = lib.conv_fwd_workspace(d)
+    ws = zeroed_scratch(nb, x.device, s) if nb else None
+    lib.conv_bias_act_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                          ldr, act, y.data_ptr(), ws.data_ptr() if nb else None, nb, d, s)
+    return y
+
+
+def detect_decode(levels, strides, anchor_grid, no):
+    """Detect eval decode (models/yolo_test.py:57-68): levels = permuted head outputs (B,na,ny,nx,no) -> (B, sum rows, no)."""
+    b, na = levels[0].shape[0], levels[0].shape[1]
+    rows = [x.shape[1] * x.shape[2] * x.shape[3] for x in levels]
+    z = torch.empty((b, sum(rows), no), dtype=torch.float32, device=levels[0].device)
+    off = 0
+    s = _stream()
+    for i, x in enumerate(levels):
+        x = x.contiguous()
+        ag = anchor_grid[i].reshape(-1).contiguous()
+        lib.detect_decode(x.data_ptr(), z.data_ptr(), b, na, x.shape[2], x.shape[3], no, sum(rows), off, float(strides[i]),
+                          ag.data_ptr(), s)
+        off += rows[i]
+    return z
+
+
+def nms(pred, conf_thres, iou_thres, class_mask, agnostic, multi_label, max_det=300, max_wh=4096.0):
+    """utils/general.py:486-580 on the device; returns (out (B,max_det,6), nout (B,) int32)."""
+    pred = pred.contiguous()
+    assert pred.dtype == torch.float32 and pred.is_cuda and pred.dim() == 3
+    b, r, no = pred.shape
+    nb = lib.nms_workspace(b, r, no - 5, int(multi_label))
+    ws = torch.empty(nb, dtype=torch.uint8, device=pred.device)
+    out = torch.zeros((b, max_det, 6), dtype=torch.float32, device=pred.device)
+    nout = torch.zeros(b, dtype=torch.int32, device=pred.device)
+    lib.nms(pred.data_ptr(), b, r, no - 5, conf_thres, iou_thres, class_mask, int(agnostic), int(multi_label), max_det,
+            max_wh, ws.data_ptr(), nb, out.data_ptr(), nout.data_ptr(), _stream())
+    return out, nout
+
+
 def linear(x, w, bias=None):
     return _ConvBias.apply(x, w, bias, 1)
 

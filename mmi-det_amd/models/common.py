@@ -58,6 +58,12 @@ class Conv(nn.Module):
                                momentum=self.bn.momentum)
 
 
+    def fuseforward(self, x, residual=None):
+        """After Model.fuse() (models/common.py:124-125): the folded conv carries the bias, BN is gone."""
+        return ops.conv_bias_act(x, self.conv.weight, self.conv.bias, stride=self.conv.stride[0], act=self._act_id(),
+                                 residual=residual)
+
+
 class Bottleneck(nn.Module):
     def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
         super().__init__()

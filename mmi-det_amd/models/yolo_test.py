@@ -22,7 +22,7 @@ from models.common import (C3, GPT, SPP, Add, Add2, AdaptiveModule3, Bottleneck,
                            GPT1_fourier, _holder_conv)
 from utils.autoanchor import check_anchor_order
 from utils.general import make_divisible
-from utils.torch_utils import initialize_weights, model_info
+from utils.torch_utils import fuse_conv_and_bn, initialize_weights, model_info
 
 logger = logging.getLogger(__name__)
 
@@ -61,20 +61,15 @@ class Detect(nn.Module):
 
     def forward(self, x):
         x = list(x)
-        z = []
         self.training |= self.export
         for i in range(self.nl):
             y = ops.conv_bias(x[i], self.m[i].weight, self.m[i].bias, 1)         # (B,ny,nx,na*no)
             x[i] = ops.head_permute(y, self.na)                                   # (B,na,ny,nx,no)
-            if not self.training:
-                bs, _, ny, nx, _ = x[i].shape
-                if self.grid[i].shape[2:4] != x[i].shape[2:4] or self.grid[i].device != x[i].device:
-                    self.grid[i] = self._make_grid(nx, ny).to(x[i].device)
-                s = x[i].sigmoid()
-                xy = (s[..., 0:2] * 2. - 0.5 + self.grid[i]) * self.stride[i]
-                wh = (s[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
-                z.append(torch.cat((xy, wh, s[..., 4:]), -1).view(bs, -1, self.no))
-        return x if self.training else (torch.cat(z, 1), x)
+        if self.training:
+            return x
+        # eval (models/yolo_test.py:57-68): sigmoid + grid/anchor decode of every level straight into the cat buffer
+        z = ops.detect_decode([t.detach() for t in x], self.stride.tolist(), self.anchor_grid, self.no)
+        return z, x
 
     @staticmethod
     def _make_grid(nx=20, ny=20):
@@ -214,8 +209,17 @@ class Model(nn.Module):
             mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
     def fuse(self):
-        raise NotImplementedError('Conv+BN folding for the inference path is scheduled after the training hot path '
-                                  '(SURVEY.md §8f-3); eval-mode forward uses the running statistics directly')
+        """Fold every Conv's BatchNorm into its convolution (models/yolo_test.py:304-312, utils/torch_utils.py:181-201).
+        Only `Conv` modules are folded, exactly as the reference's `type(m) is Conv` test (the CEM's bare conv+BN pairs
+        stay as they are)."""
+        from models.common import Conv as _Conv
+        for m in self.model.modules():
+            if type(m) is _Conv and hasattr(m, 'bn'):
+                m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, 'bn')
+                m.forward = m.fuseforward
+        self.info()
+        return self
 
     def info(self, verbose=False, img_size=640):
         model_info(self, verbose, img_size)

@@ -39,3 +39,33 @@ def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False, eps=
     with torch.no_grad():
         alpha = v / (v - iou + (1 + eps))
     return iou - (rho2 / c2 + v * alpha)
+
+
+def xywh2xyxy(x):
+    """utils/general.py:392-400 of the reference."""
+    y = x.clone()
+    y[..., 0] = x[..., 0] - x[..., 2] / 2
+    y[..., 1] = x[..., 1] - x[..., 3] / 2
+    y[..., 2] = x[..., 0] + x[..., 2] / 2
+    y[..., 3] = x[..., 1] + x[..., 3] / 2
+    return y
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=()):
+    """Reference utils/general.py:486-580 with the same signature and return type (list of (n,6) tensors
+    [xyxy, conf, cls] per image, by decreasing confidence), computed by mmi_nms on the device; the only host round trip
+    is reading the B detection counts to slice the result."""
+    from mmidet_hip import ops
+    if labels:
+        raise NotImplementedError('a-priori labels (autolabelling, general.py:519-526) are outside the detection path')
+    nc = prediction.shape[2] - 5
+    assert 0 < nc <= 64, 'class filter is a 64-bit mask'
+    mask = (1 << 64) - 1
+    if classes is not None:
+        mask = 0
+        for c in classes:
+            mask |= 1 << int(c)
+    out, nout = ops.nms(prediction.float(), float(conf_thres), float(iou_thres), mask, bool(agnostic), bool(multi_label))
+    counts = nout.tolist()
+    return [out[i, :n] for i, n in enumerate(counts)]

@@ -24,6 +24,21 @@ def initialize_weights(model):
             m.inplace = True
 
 
+def fuse_conv_and_bn(conv, bn):
+    """Inference folding of BatchNorm(eval) into the convolution (reference utils/torch_utils.py:181-201):
+    w' = w * gamma / sqrt(var + eps) per output channel, b' = beta - mean * gamma / sqrt(var + eps) (+ the scaled conv
+    bias if there was one).  The folded weight keeps the kernels' channels_last (OHWI) memory format."""
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=conv.kernel_size, stride=conv.stride,
+                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False).to(conv.weight.device)
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.eps + bn.running_var)
+        w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
+        fused.weight.data = w.contiguous(memory_format=torch.channels_last)
+        b_conv = torch.zeros_like(scale) if conv.bias is None else conv.bias.detach()
+        fused.bias.copy_(b_conv * scale + bn.bias - bn.running_mean * scale)
+    return fused
+
+
 def model_info(model, verbose=False, img_size=640):
     n_p = sum(x.numel() for x in model.parameters())
     n_g = sum(x.numel() for x in model.parameters() if x.requires_grad)

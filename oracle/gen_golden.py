@@ -5,6 +5,7 @@ arithmetic never touches, drives it with hash-generated weights
 are regenerated from the hash, outputs are stored.
 
     python oracle/gen_golden.py            # regenerate all fixtures
+    python oracle/gen_golden.py eval       # only tests/golden/eval_path.npz (Model.fuse() and NMS)
 """
 import contextlib
 import importlib.machinery
@@ -128,11 +129,50 @@ def run_model_case(Model, ComputeLoss, kind, bs, size, train):
     return out
 
 
+def gen_eval_path(Model):
+    """tests/golden/eval_path.npz: (1) the reference's Model.fuse() (yolo_test.py:304-312) + eval forward on the tiny
+    graphs; (2) the reference's non_max_suppression (general.py:486-580) run around oracle.ref_nms.greedy_nms, which
+    stands in for the torchvision.ops.nms call the image cannot provide (see oracle/ref_nms.py: that part is unpinned)."""
+    from oracle import ref_nms
+    o = {}
+    quiet = io.StringIO()
+    for kind in ('fourier', 'add'):
+        with contextlib.redirect_stdout(quiet):
+            cfg = tiny_cfg(kind)
+            model = Model(deepcopy(cfg))
+        sd = model.state_dict()
+        portable_init.fill_(sd)
+        model.load_state_dict(sd)
+        imgs, _ = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=1)
+        x = imgs.float() / 255
+        model.eval()
+        with contextlib.redirect_stdout(quiet), torch.no_grad():
+            model.fuse()
+            (z, _), _ = model(x[:, :3], x[:, 3:])
+        o['%s.z_fused' % kind] = z.numpy()
+        o['%s.fused_w' % kind] = model.model[1].conv.weight.detach().numpy()
+        o['%s.fused_b' % kind] = model.model[1].conv.bias.detach().numpy()
+    import utils.general as G
+    sys.modules['torchvision'].ops.nms = ref_nms.greedy_nms
+    G.torchvision.ops.nms = ref_nms.greedy_nms
+    for name, seed, rows, kw in ref_nms.NMS_CASES:
+        pred = ref_nms.synth_predictions(seed, rows=rows)
+        out = G.non_max_suppression(pred.clone(), **kw)
+        for i, t in enumerate(out):
+            o['nms.%s.%d' % (name, i)] = t.numpy()
+    fn = os.path.join(OUT, 'eval_path.npz')
+    np.savez_compressed(fn, **o)
+    print('wrote', fn, os.path.getsize(fn))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     Model, ComputeLoss, bbox_iou, extract_frequency2, Seperation_loss = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'eval':      # only the §8 f-3 fixtures
+        gen_eval_path(Model)
+        return
 
     for kind, bs, size in (('fourier', 2, 128), ('add', 2, 128)):
         for train in (True, False):
@@ -183,6 +223,7 @@ def main():
             o['%s.anch%d' % (tag, i)] = anch[i].numpy()
             o['%s.idx%d' % (tag, i)] = torch.stack(indices[i]).numpy() if len(indices[i][0]) or True else None
     np.savez_compressed(os.path.join(OUT, 'build_targets.npz'), **o)
+    gen_eval_path(Model)
     print('done')
 
 

@@ -36,6 +36,22 @@ class Conv(nn.Module):
     def forward(self, x):
         return self.act(self.bn(self.conv(x)))
 
+    def fuseforward(self, x):  # common.py:124-125
+        return self.act(self.conv(x))
+
+
+def fuse_conv_and_bn(conv, bn):
+    """utils/torch_utils.py:181-201: W' = diag(gamma / sqrt(eps + var)) W,  b' = beta - gamma * mean / sqrt(var + eps)."""
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=conv.kernel_size, stride=conv.stride,
+                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False)
+    w_conv = conv.weight.clone().view(conv.out_channels, -1)                                  # :192
+    w_bn = torch.diag(bn.weight.div(torch.sqrt(bn.eps + bn.running_var)))                     # :193
+    fused.weight.copy_(torch.mm(w_bn, w_conv).view(fused.weight.shape))                       # :194
+    b_conv = torch.zeros(conv.weight.size(0)) if conv.bias is None else conv.bias             # :197
+    b_bn = bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))  # :198
+    fused.bias.copy_(torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn)                # :199
+    return fused
+
 
 class Bottleneck(nn.Module):
     """x + cv2(cv1(x)), 1x1 then 3x3.  common.py:602-613."""
@@ -470,6 +486,15 @@ class Model(nn.Module):
             b.data[:, 4] += math.log(8 / (640 / s) ** 2)
             b.data[:, 5:] += math.log(0.6 / (m.nc - 0.99))
             mi.bias = nn.Parameter(b.view(-1), requires_grad=True)
+
+    def fuse(self):  # yolo_test.py:304-312 (only `type(m) is Conv`: the CEM's conv+BN pairs are left alone)
+        with torch.no_grad():
+            for m in self.model.modules():
+                if type(m) is Conv and hasattr(m, 'bn'):
+                    m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                    delattr(m, 'bn')
+                    m.forward = m.fuseforward
+        return self
 
     def forward(self, x, x2, augment=False, profile=False):
         return self.forward_once(x, x2)

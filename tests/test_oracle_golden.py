@@ -108,3 +108,38 @@ def test_build_targets_full_size_bit_exact(tag, bs, per):
         assert np.array_equal(torch.stack(idx[i]).numpy(), g['%s.idx%d' % (tag, i)])
         assert np.array_equal(tbox[i].numpy(), g['%s.tbox%d' % (tag, i)])
         assert np.array_equal(anch[i].numpy(), g['%s.anch%d' % (tag, i)])
+
+
+# ---- evaluation path: Model.fuse() and non_max_suppression -------------------------------------------
+@pytest.mark.parametrize('kind', ['fourier', 'add'])
+def test_oracle_fuse_matches_reference(kind):
+    """oracle fuse_conv_and_bn / Model.fuse() against the reference's own (utils/torch_utils.py:181-201)."""
+    from oracle import portable_init
+    from oracle.ref_model import Model
+    g = np.load(os.path.join(GOLDEN, 'eval_path.npz'))
+    cfg = tiny_cfg(kind)
+    m = Model(cfg)
+    m.load_state_dict(portable_init.fill_(m.state_dict()))
+    imgs, _ = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=1)
+    x = imgs.float() / 255
+    m.eval().fuse()
+    with torch.no_grad():
+        (z, _), _ = m(x[:, :3], x[:, 3:])
+    np.testing.assert_allclose(m.model[1].conv.weight.numpy(), g['%s.fused_w' % kind], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(m.model[1].conv.bias.numpy(), g['%s.fused_b' % kind], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(z.numpy(), g['%s.z_fused' % kind], rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_nms_matches_reference_wrapper():
+    """oracle.ref_nms.non_max_suppression against the reference's function (general.py:486-580) run around the same
+    greedy NMS: every case bit-equal (same torch ops in the same order)."""
+    from oracle import ref_nms
+    g = np.load(os.path.join(GOLDEN, 'eval_path.npz'))
+    for name, seed, rows, kw in ref_nms.NMS_CASES:
+        pred = ref_nms.synth_predictions(seed, rows=rows)
+        out = ref_nms.non_max_suppression(pred, **kw)
+        for i, t in enumerate(out):
+            ref = g['nms.%s.%d' % (name, i)]
+            assert tuple(t.shape) == ref.shape, (name, i, t.shape, ref.shape)
+            assert np.array_equal(t.numpy(), ref), (name, i)
+    assert g['nms.none.0'].shape[0] == 0 and g['nms.test_py.0'].shape[0] == 300
