@@ -220,6 +220,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-gemm', default=None, help='write the per-shape GEMM time table of the roofline pass here')
     ap.add_argument('--ddp', action='store_true', help='run the data-parallel code path even on one GPU (world size 1)')
+    ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
 
@@ -254,11 +255,15 @@ def main():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = args.dropout
     model.train()
-    # hipGraph replay (the eager step is host-bound: ~135 ms of launch enqueueing per step).  One GPU: the whole step is
-    # one graph.  Data parallel: forward+backward is the graph, then the bucket all-reduces (RCCL) and the one-launch
-    # optimizer follow on the same stream (--no-graph: eager, collectives issued by grad-ready hooks during backward).
-    use_graph = not args.no_graph
-    ts = TrainStep(model, nc, 640, bs, world_size=world, accumulate=1, graph=use_graph)
+    # Launch mode.  "eager": every kernel enqueued by the host each step (~120-135 ms of host time per step, so the GPU
+    # stays the bottleneck as long as a core is free), wgrad on a side stream next to dgrad.  "graph": hipGraph replay --
+    # one GPU: the whole step is one graph; data parallel: forward+backward is the graph, then the bucket all-reduces
+    # (RCCL) and the one-launch optimizer follow on the same stream.  On this ROCm a replay costs about as much host time
+    # as the eager enqueue and leaves larger gaps between dependent kernels, so neither mode wins everywhere: "auto"
+    # (default) times three warm-up steps of each and keeps the faster one for the timed region.
+    mode = 'eager' if args.no_graph else args.mode
+    use_graph = False
+    ts = TrainStep(model, nc, 640, bs, world_size=world, accumulate=1, graph=False)
     if ddp:
         from mmidet_hip.ddp import GradReducer
         red = GradReducer(list(model.parameters()))
@@ -284,9 +289,41 @@ def main():
         ts.step(imgs, tg)
         torch.cuda.synchronize()
         note('warmup step %d done, %.1f GB allocated' % (i, torch.cuda.max_memory_allocated() / 2 ** 30))
+
+    def probe(n=3):
+        """-> (ms per step, host ms per step spent enqueueing), max over ranks"""
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            ts.step(imgs, tg)
+        te = time.perf_counter() - t
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t, te], device=dev, dtype=torch.float64)
+        if ddp:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+        return float(t[0]) / n * 1e3, float(t[1]) / n * 1e3
+
+    probes = {}
+    if mode == 'auto':
+        # Eager is kept when the host finishes enqueueing a step well before the GPU finishes running it (then the GPU
+        # never waits for the host); the graph is only captured -- 25 GB of private pool, thousands of retained tensors
+        # that measurably slow later eager steps -- when that is not the case.
+        ms, enq = probe()
+        probes['eager'] = round(ms, 1)
+        probes['eager_host_enqueue'] = round(enq, 1)
+        if enq > 0.92 * ms:
+            ts.use_graph = True
+            ts.step(imgs, tg)                             # capture (runs two eager steps on a side stream first)
+            torch.cuda.synchronize()
+            probes['graph'] = round(probe()[0], 1)
+            ts.use_graph = probes['graph'] < probes['eager']
+        note('probe: %s -> %s' % (probes, 'graph' if ts.use_graph else 'eager'))
+    elif mode == 'graph':
+        ts.use_graph = True
+        ts.step(imgs, tg)
+        torch.cuda.synchronize()
+    use_graph = ts.use_graph
     barrier()
-    if not args.no_roofline and not use_graph:
-        timer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, items = ts.step(imgs, tg)
@@ -295,9 +332,10 @@ def main():
     dt = time.perf_counter() - t0
     timer.on = False
     roof_steps = args.steps
-    if not args.no_roofline and use_graph:
-        # Roofline pass: the SAME step issued eagerly right after the timed region (same kernels, shapes, streams), so
-        # that HIP events can bracket every implicit-GEMM launch; a replayed graph offers no per-kernel event points.
+    if not args.no_roofline:
+        # Roofline pass: the SAME step issued eagerly right after the timed region (same kernels, shapes, streams) with HIP
+        # events around every implicit-GEMM launch; kept out of the timed region because a replayed graph offers no
+        # per-kernel event points and, in eager mode, 2 x 1100 event records per step are host time the step does not have.
         ts.use_graph = False
         roof_steps = min(args.steps, 3)
         ts.step(imgs, tg)
@@ -326,7 +364,8 @@ def main():
                                     's_add': 'yolov5s fusion_add (fusion modules off), nc=9'}[args.workload],
                        'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,640,640)', 'dropout_p': args.dropout,
                        'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
-                       'launch_mode': ('eager' if not use_graph else 'whole-step hipGraph replay' if not ddp else
+                       'launch_mode_probe_ms': probes,
+                       'launch_mode': ('eager, wgrad on a side stream' if not use_graph else 'whole-step hipGraph replay' if not ddp else
                                        'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
                        'loss': [round(float(v), 5) for v in items.tolist()]},
@@ -342,8 +381,7 @@ def main():
                                'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit GEMM: conv+linear fwd, dgrad, wgrad)',
                                'launches_per_step': len(timer.recs) // max(roof_steps, 1),
                                'gemm_busy_ms_per_step': round(tot_ms / roof_steps, 3),
-                               'measured_on': ('%d eager steps right after the timed graph-replay region' % roof_steps) if use_graph
-                               else 'the timed region itself',
+                               'measured_on': '%d eager steps right after the timed region' % roof_steps,
                                'timing': 'HIP events on each launch stream; busy = union of launch intervals (dgrad and wgrad overlap on two streams)',
                                'per_call': {k: {'TFLOP/s_while_sharing_the_chip': round(v[0] / (v[1] * 1e-3) / 1e12, 2), 'sum_launch_ms_per_step': round(v[1] / roof_steps, 3),
                                                 'launches_per_step': v[2] // roof_steps} for k, v in per.items()},

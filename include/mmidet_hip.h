@@ -58,6 +58,9 @@ int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
  * shape with >= 2 K slabs (lets small test shapes take the schedule), n < 0 = schedule off.  Returns the old value.
  * Changes what the *_workspace() and row_blocks() queries answer: set it before planning a call, not between. */
 int mmi_set_streamk_slots(int slots);
+/* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
+ * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
+int mmi_set_tile_override(int bm, int bn);
 size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d);
 int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials, void* workspace,
                  size_t workspace_bytes, const mmi_conv_desc* d, void* stream);

@@ -754,8 +754,17 @@ struct FwdPlan {
   int bm, bn, mtiles, ntiles;
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
+int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
 FwdPlan plan_tiles(int64_t M, int Ncol) {
   FwdPlan f;
+  if (g_tile_bm > 0) {
+    f.bm = g_tile_bm;
+    f.bn = g_tile_bn;
+    f.mtiles = cdiv(M, f.bm);
+    f.ntiles = cdiv(Ncol, f.bn);
+    f.sk_grid = 0;
+    return f;
+  }
   f.bn = Ncol > 64 ? 128 : 64;
   f.bm = 128;
   // small problems: shrink the tile until there are >= 2 workgroups per CU (256 CUs)
@@ -800,35 +809,47 @@ int sk_occupancy(int bn) {
   return c;
 }
 
-// Stream-K pays when the tile count is a poor multiple of the chip (a kernel's time grows in steps of one workgroup per
-// CU: 769 tiles cost as much as 1024) and K is long enough to amortise the partial-tile traffic.
+// Schedule choice for the vector kernels.  A kernel's time grows in steps of one workgroup per CU (769 tiles of 128x128
+// cost as much as 1024), so:
+//  * long K (>= 32 slabs per resident workgroup): stream-K over 128-wide tiles unless one workgroup per tile already
+//    fills the chip evenly (>= 93 % of the last "layer" of 256);
+//  * short K (1x1 convs, token projections; tools/sweep_tiles.py): one workgroup per tile; 128-wide tiles only when they
+//    fill the chip evenly (>= 88 %), else 64x64 tiles, whose finer grain and 5 resident workgroups per CU lose less to
+//    the last layer than they lose in per-tile efficiency (+10..16 % on the yolov5l 1x1 layers).
 template <bool DGRAD>
 FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
   FwdPlan f = plan_tiles(M, Ncol);
   if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(Ncol, 64);
   static const bool off = getenv("MMIDET_NO_STREAMK") != nullptr;
   const int nk = cdiv(Ktot, BK);
-  if (!vec || !allow_sk || off || g_sk_slots < 0 || nk < (g_sk_slots > 0 ? 2 : 16)) return f;
+  if (!vec || !allow_sk || g_tile_bm > 0) return f;
   FwdPlan g;
   g.bm = 128;
   g.bn = Ncol > 64 ? 128 : 64;
   g.mtiles = cdiv(M, 128);
   g.ntiles = cdiv(Ncol, g.bn);
+  g.sk_grid = 0;
   const int64_t tiles = (int64_t)g.mtiles * g.ntiles;
   const int cus = device_cus();
   const int slots = g_sk_slots > 0 ? g_sk_slots : cus * sk_occupancy<DGRAD>(g.bn);
-  if (tiles > SK_MAX_TILES || tiles * nk < (int64_t)slots || tiles * nk >= (1LL << 31)) return f;
-  if (g_sk_slots == 0) {
-    // measured on the yolov5l shapes: below ~32 slabs per workgroup the partial-tile traffic eats the gain
-    if (tiles * nk < (int64_t)32 * slots) return f;
-    const double layers = (double)tiles / cus, dp_eff = layers / ceil(layers);
-    if (tiles >= slots && dp_eff >= 0.93) {  // one workgroup per tile already fills the chip evenly
-      g.sk_grid = 0;
-      return g;
-    }
+  const double layers = (double)tiles / cus, dp_eff = layers / ceil(layers);
+  const bool sk_ok = !off && g_sk_slots >= 0 && nk >= (g_sk_slots > 0 ? 2 : 16) && tiles <= SK_MAX_TILES &&
+                     tiles * nk >= (int64_t)(g_sk_slots > 0 ? 1 : 32) * slots && tiles * nk < (1LL << 31);
+  if (sk_ok) {
+    if (g_sk_slots == 0 && tiles >= slots && dp_eff >= 0.93) return g;  // already even
+    g.sk_grid = slots;
+    return g;
   }
-  g.sk_grid = slots;
-  return g;
+  static const int mode = getenv("MMIDET_SHORTK_TILES") ? atoi(getenv("MMIDET_SHORTK_TILES")) : 0;
+  if (mode == 1) {  // experiment: finest balance (best standalone)
+    if (tiles >= slots && dp_eff >= 0.88) return g;
+    f.bm = f.bn = 64;
+    f.mtiles = cdiv(M, 64);
+    f.ntiles = cdiv(Ncol, 64);
+    return f;
+  }
+  if (mode == 2 && tiles >= 128) return g;  // experiment: always the most efficient tile, let the other lane fill the chip
+  return f;
 }
 
 size_t sk_workspace_bytes(const FwdPlan& f) {
@@ -902,6 +923,14 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int mmi_set_tile_override(int bm, int bn) {
+  const bool ok = (bm == 0 && bn == 0) || (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64);
+  MMI_CHECK_ARG(ok, "mmi_set_tile_override: (%d,%d) is not a kernel variant (128x128, 128x64, 64x64; 0,0 = automatic)", bm, bn);
+  g_tile_bm = bm;
+  g_tile_bn = bn;
+  return MMI_OK;
+}
 
 extern "C" int mmi_set_streamk_slots(int slots) {
   const int old = g_sk_slots;

@@ -100,7 +100,13 @@ def _ohwi(w):
 
 OVERLAP_WGRAD = __import__("os").environ.get("MMIDET_OVERLAP_WGRAD", "1") != "0"   # weight-gradient GEMM on a side HIP stream next to dgrad
 SHARED_SIDE = __import__("os").environ.get("MMIDET_SHARED_SIDE", "0") == "1"   # one wgrad stream for both backbone lanes
+# Deferred join: the lane never waits for its wgrad stream per layer; the operands are kept alive in _pending and the
+# caller joins once after backward (join_pending).  Nobody may read a weight gradient before that: valid while .grad is
+# None at backward time (autograd then adopts dw without touching it), i.e. not with the DDP flat buckets.
+DEFER_JOIN = False   # switched on by TrainStep around its own backward only
 _side_streams = {}
+_pending = []
+_pending_sides = {}
 
 
 def _side_stream(device):
@@ -108,7 +114,7 @@ def _side_stream(device):
     key = (device, 0 if SHARED_SIDE else _stream())
     s = _side_streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=device)
+        s = torch.cuda.Stream(device=device, priority=int(__import__("os").environ.get("MMIDET_SIDE_PRIORITY", "0")))
         _side_streams[key] = s
     return s
 
@@ -128,6 +134,9 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False):
         side.wait_stream(main)
         lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
                        d, side.cuda_stream)
+        if DEFER_JOIN:
+            _pending.append((dy, x))
+            _pending_sides[side.cuda_stream] = side
     else:
         ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
         lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
@@ -136,7 +145,17 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False):
 
 
 def _join_side(device):
-    torch.cuda.current_stream().wait_stream(_side_stream(device))
+    if not DEFER_JOIN:
+        torch.cuda.current_stream().wait_stream(_side_stream(device))
+
+
+def join_pending():
+    """After backward (deferred-join mode): the current stream waits for every wgrad stream, then the operands go."""
+    cur = torch.cuda.current_stream()
+    for side in _pending_sides.values():
+        cur.wait_stream(side)
+    _pending_sides.clear()
+    _pending.clear()
 
 
 class _ConvBnAct(Function):

@@ -70,7 +70,7 @@ def build_optimizer(model, hyp, total_batch_size, fused=True, ema_model=None):
 
 class TrainStep:
     def __init__(self, model, nc, imgsz, batch_size, world_size=1, reducer=None, hyp=None, ema=True, accumulate=None,
-                 fused_optimizer=True, graph=False):
+                 fused_optimizer=True, graph=False, defer_join=True):
         self.model = model
         self.world_size = world_size
         self.reducer = reducer
@@ -85,6 +85,7 @@ class TrainStep:
         self.compute_loss = ComputeLoss(model)
         self.ni = 0
         self.use_graph = graph
+        self.defer_join = defer_join
         self._graph = None
         assert not (graph and self.accumulate != 1), 'graph mode captures one full step: accumulate must be 1'
         assert not (graph and not fused_optimizer), 'graph mode needs the fused optimizer (device-resident hyper-parameters)'
@@ -92,6 +93,10 @@ class TrainStep:
     # ---- the step body (eager; also what gets captured) ----------------------------------------------------------------
     def _body(self, imgs_u8, targets, reduce=True):
         model = self.model
+        # wgrad overlap with ONE join after backward (ops.join_pending) instead of one per layer: allowed when nobody reads a
+        # weight gradient during backward, i.e. .grad is None (adopted untouched by autograd) -- not with the data-parallel
+        # flat buckets or gradient accumulation, which add into existing .grad tensors as soon as a layer is done.
+        defer = self.defer_join and self.reducer is None and self.accumulate == 1 and ops.OVERLAP_WGRAD
         F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
         if imgs_u8.dtype == torch.uint8:
             rgb, ir = ops.u8_pair_to_nhwc(imgs_u8)                                      # train.py:743-745 in one kernel
@@ -105,7 +110,12 @@ class TrainStep:
         reduce = reduce and self.reducer is not None
         if reduce:
             self.reducer.prepare()
-        loss.sum().backward()                                                           # train.py:796
+        ops.DEFER_JOIN = defer
+        try:
+            loss.sum().backward()                                                       # train.py:796
+        finally:
+            ops.DEFER_JOIN = False
+            ops.join_pending()
         if reduce:
             self.reducer.finish()                                                       # mean over ranks, as DDP
         return loss, items
@@ -157,12 +167,19 @@ class TrainStep:
         return self._loss, self._items
 
     def _capture(self, imgs_u8, targets):
-        # Capture keeps ONE level of stream forking.  The twin backbone lanes (RGB/IR on two HIP streams) capture fine and
-        # are worth more (175 vs 184 ms/step) than the per-layer dgrad||wgrad side stream; with both,
-        # hipStreamEndCapture of ROCm 7.2 segfaults (nested forks, ~4000 nodes), so the wgrad overlap is an eager-mode
-        # feature and is switched off for the captured step.
+        # The captured step keeps ONE level of stream forking: the twin backbone lanes (RGB/IR on two HIP streams).  The
+        # per-layer dgrad||wgrad fork inside a lane makes hipStreamEndCapture of this ROCm segfault (nested forks); the
+        # deferred-join form captures, but replays slower than without (158 vs 153 ms/step), so wgrad overlap is an
+        # eager-mode feature and is off while capturing.
+        prev = ops.OVERLAP_WGRAD
         if self.model.two_streams:
             ops.OVERLAP_WGRAD = False
+        try:
+            self._capture_locked(imgs_u8, targets)
+        finally:
+            ops.OVERLAP_WGRAD = prev
+
+    def _capture_locked(self, imgs_u8, targets):
         self._imgs, self._targets = imgs_u8.clone(), targets.clone()
         side = torch.cuda.Stream(device=imgs_u8.device)
         side.wait_stream(torch.cuda.current_stream())

@@ -168,13 +168,16 @@ def test_data_parallel_graph_step_matches_whole_step_graph():
         m2, ts2, _ = make(graph=True)
         ts2.reducer = GradReducer(list(m2.parameters()))
         batches = [batch(cfg, 30 + i) for i in range(3)]
-        for imgs, tg in batches:
+        # Two trainings of the same net are not bit-identical run to run (fp32 atomics in a few reductions); by the third
+        # step a flipped max-pool tie moves the loss by ~0.25 % (tools/det_check.py shows the same spread between two
+        # identical single-GPU runs), hence the per-step tolerances.
+        for (imgs, tg), tol in zip(batches, (1e-4, 1e-4, 6e-3)):
             l1, i1 = ts1.step(imgs, tg)
             l2, i2 = ts2.step(imgs, tg)
-            close(l1, l2, what='loss', tol=2e-3)
-            close(i1, i2, what='items', tol=2e-3)
-        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=2e-3)
-        close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=2e-3)
+            close(l1, l2, what='loss', tol=tol)
+            close(i1, i2, what='items', tol=tol)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=6e-3)
+        close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=6e-3)
         assert all(float(b.flat.abs().max()) == 0.0 for b in ts2.reducer.buckets), 'buckets are zeroed after the update'
     finally:
         dist.destroy_process_group()
