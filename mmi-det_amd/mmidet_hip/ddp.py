@@ -15,6 +15,11 @@ import torch
 import torch.distributed as dist
 
 
+# cost-attribution switches (tools only): 'noreduce' = hooks without collectives, 'nohooks' = all buckets reduced in finish(),
+# 'nosidewait' = collectives do not wait for the wgrad streams (WRONG results; timing experiments only)
+_DEBUG = __import__('os').environ.get('MMIDET_DDP_DEBUG', '')
+
+
 class _Bucket:
     __slots__ = ('flat', 'params', 'pending', 'work', 'launched')
 
@@ -23,7 +28,13 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, params, bucket_mb=256, process_group=None):
+    """direct=True (CUDA): gradients are not accumulated into the buckets by autograd.  `.grad` is None when backward starts;
+    the weight-gradient kernels write straight into the parameter's bucket view (ops.GRAD_SLOTS) and autograd adopts that
+    view as `.grad`; the remaining small gradients (BatchNorm/LayerNorm/bias vectors, pos_emb) are copied into their view by
+    the grad-ready hook.  That removes a read-modify-write pass over 832 MB per step and lets TrainStep keep the
+    deferred-join wgrad overlap under data parallelism (nobody reads a weight gradient during backward)."""
+
+    def __init__(self, params, bucket_mb=256, process_group=None, direct=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         params = [p for p in params if p.requires_grad]
@@ -41,9 +52,20 @@ class GradReducer:
         for b in self.buckets:
             for p in b.params:
                 self._of[p] = b
-                p.register_post_accumulate_grad_hook(self._ready)
+                if _DEBUG != 'nohooks':
+                    p.register_post_accumulate_grad_hook(self._ready)
         self.enabled = True      # False while a hipGraph of forward+backward is captured/replayed: see reduce_now()
         self.cuda = params[0].is_cuda
+        self.direct = self.cuda if direct is None else (direct and self.cuda)
+        self._slot = {}
+        if self.direct:
+            from . import ops
+            self._ops = ops
+            for b in self.buckets:
+                for p in b.params:
+                    self._slot[p] = p.grad                      # the bucket view made by _make
+                    ops.GRAD_SLOTS[p.data_ptr()] = p.grad
+                    p.grad = None
         self.comm = torch.cuda.Stream(device=params[0].device) if self.cuda else None
         self.avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else dist.ReduceOp.SUM
 
@@ -69,16 +91,29 @@ class GradReducer:
 
     def _launch(self, b):
         b.launched = True
+        if _DEBUG == 'noreduce':
+            return
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            sides = self._ops.side_streams_in_flight() if (self.direct and _DEBUG != 'nosidewait') else []
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)                      # the bucket's last gradient has been written
+                for sd in sides:                              # ... including weight gradients still running on a wgrad stream
+                    self.comm.wait_stream(sd)
                 b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
         else:
             b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
 
     def _ready(self, p):
+        if self.direct:
+            slot = self._slot[p]
+            if p.grad.data_ptr() != slot.data_ptr():          # produced elsewhere (small vectors): move it into the bucket
+                if p.data_ptr() in self._ops.SLOT_HANDED_OUT:
+                    raise RuntimeError('autograd copied a gradient that was written into its bucket view instead of '
+                                       'adopting it (the copy may have read it before its wgrad stream finished)')
+                slot.copy_(p.grad)
+                p.grad = slot.detach()
         if not self.enabled:
             return
         b = self._of[p]
@@ -92,6 +127,8 @@ class GradReducer:
             if not b.launched:
                 self._launch(b)
         for b in self.buckets:
+            if b.work is None:
+                continue
             b.work.wait()
             if self.avg == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
@@ -104,6 +141,14 @@ class GradReducer:
             if self.avg == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)
 
-    def zero(self):
+    def zero(self, keep_grads=False):
+        """After the optimizer step.  direct: every gradient is rewritten in full next step, so dropping `.grad` is all
+        (keep_grads: a replayed graph rewrites the same views without going through autograd again)."""
+        if self.direct:
+            self._ops.SLOT_HANDED_OUT.clear()
+            if not keep_grads:
+                for p in self._slot:
+                    p.grad = None
+            return
         for b in self.buckets:
             b.flat.zero_()

@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from . import lib
-from .ops import _nrows, _stream, rows_of, scratch
+from .ops import _nrows, _stream, grad_like, rows_of, scratch
 
 _drop_counter = [0]
 _seed_state = {}
@@ -44,6 +44,7 @@ class _LayerNorm(Function):
         lib.layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), rows, c, eps,
                           _stream())
         ctx.save_for_backward(x, gamma, stats)
+        ctx.beta = beta
         return y
 
     @staticmethod
@@ -53,7 +54,7 @@ class _LayerNorm(Function):
         c = x.shape[-1]
         rows = _nrows(x)
         dx = torch.empty_like(x)
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        dg, db = grad_like(gamma), grad_like(ctx.beta)
         part = scratch(lib.layernorm_bwd_parts(rows) * 2 * c, x.device)
         lib.layernorm_bwd(x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dy.data_ptr(), dx.data_ptr(), part.data_ptr(),
                           dg.data_ptr(), db.data_ptr(), rows, c, _stream())

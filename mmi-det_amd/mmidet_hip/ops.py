@@ -104,6 +104,10 @@ SHARED_SIDE = __import__("os").environ.get("MMIDET_SHARED_SIDE", "0") == "1"   #
 # caller joins once after backward (join_pending).  Nobody may read a weight gradient before that: valid while .grad is
 # None at backward time (autograd then adopts dw without touching it), i.e. not with the DDP flat buckets.
 DEFER_JOIN = False   # switched on by TrainStep around its own backward only
+# Data parallel: weight data_ptr -> view of the reducer's flat bucket.  The wgrad kernel then writes the gradient where
+# the collective reads it, and autograd adopts that view as .grad (no accumulate pass, no pack copy): ddp.GradReducer.
+GRAD_SLOTS = {}
+SLOT_HANDED_OUT = set()   # weights whose gradient was written into its slot this step (checked by the reducer's hook)
 _side_streams = {}
 _pending = []
 _pending_sides = {}
@@ -119,13 +123,23 @@ def _side_stream(device):
     return s
 
 
-def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False):
+def grad_like(t):
+    """Output tensor for the gradient of parameter tensor `t`: its bucket view under data parallelism (see GRAD_SLOTS),
+    else fresh memory of the parameter's layout."""
+    slot = GRAD_SLOTS.get(t.data_ptr())
+    if slot is not None and slot.shape == t.shape and slot.stride() == t.stride():
+        SLOT_HANDED_OUT.add(t.data_ptr())
+        return slot.detach()        # a fresh alias (sole owner), so that AccumulateGrad adopts it instead of cloning
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
+def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     """dw = dy^T x.  With overlap=True the kernel is enqueued on the side stream behind everything already on the
     current stream; the caller must `_join_side()` before the current stream (or anyone else) touches dw.  dgrad and wgrad
     of one layer are independent, and two co-running grids fill each other's partial last wave (the fp32-MFMA kernels
     lose up to a third of the chip to wave quantisation when they run alone)."""
-    dw = torch.empty_strided(w.shape, w.stride(), dtype=w.dtype, device=w.device)
-    db = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if want_bias else None
+    dw = grad_like(w)
+    db = (grad_like(bias) if bias is not None else torch.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
     dbp = db.data_ptr() if want_bias else None
     nbytes = lib.conv_wgrad_workspace(d)
     if overlap:
@@ -147,6 +161,11 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False):
 def _join_side(device):
     if not DEFER_JOIN:
         torch.cuda.current_stream().wait_stream(_side_stream(device))
+
+
+def side_streams_in_flight():
+    """wgrad streams with work the current stream has not joined yet (deferred-join mode)."""
+    return list(_pending_sides.values())
 
 
 def join_pending():
@@ -203,8 +222,8 @@ class _ConvBnAct(Function):
         lib.bn_act_bwd_reduce(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               part.data_ptr(), rows, cout, act, s)
         dy = torch.empty_like(y)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        dgamma = grad_like(gamma)
+        dbeta = grad_like(beta)
         lib.bn_act_bwd_apply(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                              part.data_ptr(), nparts, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), rows, cout,
                              act, 0 if training else 1, s)
@@ -243,6 +262,7 @@ class _ConvBias(Function):
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
         conv_fwd(x, w, bias, y, None, d, _stream())
         ctx.save_for_backward(x, w)
+        ctx.bias = bias            # (only its address is needed in backward: where the bias gradient goes)
         ctx.cfg = (d, bias is not None)
         return y
 
@@ -260,7 +280,7 @@ class _ConvBias(Function):
         if ctx.needs_input_grad[1]:
             dwd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.ldx, lddy)
             if want_db:   # the bias gradient falls out of the weight-gradient kernel's dy tiles
-                dw, db = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both, want_bias=True)
+                dw, db = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both, want_bias=True, bias=ctx.bias)
             else:
                 dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
@@ -268,7 +288,7 @@ class _ConvBias(Function):
             conv_dgrad(dy, w, dx, dd, s)
         if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
-            db = torch.empty(d.Cout, dtype=x.dtype, device=x.device)
+            db = grad_like(ctx.bias)
             part = scratch(lib.bn_bwd_parts(rows) * d.Cout, x.device)
             lib.colsum(dy.data_ptr(), lddy, rows, d.Cout, part.data_ptr(), db.data_ptr(), s)
         if both:

@@ -96,7 +96,8 @@ class TrainStep:
         # wgrad overlap with ONE join after backward (ops.join_pending) instead of one per layer: allowed when nobody reads a
         # weight gradient during backward, i.e. .grad is None (adopted untouched by autograd) -- not with the data-parallel
         # flat buckets or gradient accumulation, which add into existing .grad tensors as soon as a layer is done.
-        defer = self.defer_join and self.reducer is None and self.accumulate == 1 and ops.OVERLAP_WGRAD
+        direct = self.reducer is None or getattr(self.reducer, 'direct', False)
+        defer = self.defer_join and direct and self.accumulate == 1 and ops.OVERLAP_WGRAD
         F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
         if imgs_u8.dtype == torch.uint8:
             rgb, ir = ops.u8_pair_to_nhwc(imgs_u8)                                      # train.py:743-745 in one kernel
@@ -132,7 +133,7 @@ class TrainStep:
             if self.ema is not None:
                 self.ema.update(self.model)
         if self.reducer is not None:
-            self.reducer.zero()                                                         # grads are views of flat buckets
+            self.reducer.zero(keep_grads=in_capture)                                    # grads are views of flat buckets
         else:
             self.optimizer.zero_grad(set_to_none=True)
 

@@ -105,15 +105,17 @@ def test_whole_step_graph_matches_eager():
     # the capture pass itself runs two warm-up steps on the first batch: mirror them on the eager side
     for _ in range(2):
         ts2.step(*batches[0])
-    for imgs, tg in batches:
+    # (two trainings are not bit-identical run to run -- fp32 atomics in a few reductions -- and a flipped max-pool tie
+    # moves a later loss by ~0.25 %, see tools/det_check.py: tight on the first steps, loose afterwards)
+    for (imgs, tg), tol in zip(batches, (1e-3, 6e-3, 6e-3, 6e-3)):
         l1, i1 = ts1.step(imgs, tg)
         l2, i2 = ts2.step(imgs, tg)
-        close(l1, l2, what='loss', tol=2e-3)
-        close(i1, i2, what='items', tol=2e-3)
+        close(l1, l2, what='loss', tol=tol)
+        close(i1, i2, what='items', tol=tol)
     w1, w2 = m1.model[1].conv.weight, m2.model[1].conv.weight
-    close(w1, w2, what='weights after 4 graph replays', tol=2e-3)
+    close(w1, w2, what='weights after 4 graph replays', tol=6e-3)
     # (with d = 0.9999*(1-exp(-n/2000)) ~ 0.003 after 6 updates the EMA is almost the latest weights: same tolerance)
-    close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=2e-3)
+    close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=6e-3)
 
 
 def test_graph_replay_draws_fresh_dropout_masks():
@@ -178,6 +180,46 @@ def test_data_parallel_graph_step_matches_whole_step_graph():
             close(i1, i2, what='items', tol=tol)
         close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=6e-3)
         close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=6e-3)
-        assert all(float(b.flat.abs().max()) == 0.0 for b in ts2.reducer.buckets), 'buckets are zeroed after the update'
     finally:
+        from mmidet_hip import ops
+        ops.GRAD_SLOTS.clear()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_eager_writes_gradients_into_the_buckets():
+    """Eager N>1 structure (world size 1): weight gradients are written by the wgrad kernels straight into the reducer's
+    flat buckets (adopted by autograd, no accumulate pass), the small vectors are copied in by the grad-ready hook, the
+    deferred-join wgrad overlap stays on; result = the single-GPU eager step."""
+    import os
+    import torch.distributed as dist
+    from mmidet_hip import ops
+    from mmidet_hip.ddp import GradReducer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+    try:
+        m1, ts1, cfg = make(graph=False)
+        m2, ts2, _ = make(graph=False)
+        red = ts2.reducer = GradReducer(list(m2.parameters()))
+        assert red.direct and all(p.grad is None for p in m2.parameters())
+        imgs, tg = batch(cfg, 40)
+        # one backward by hand: where did the gradients land?
+        ts2._body(imgs, tg)
+        w, gam = m2.model[1].conv.weight, m2.model[1].bn.weight
+        assert w.grad.data_ptr() == red._slot[w].data_ptr(), 'conv weight gradient lives in its bucket view'
+        assert gam.grad.data_ptr() == red._slot[gam].data_ptr(), 'BN gradient was moved into its bucket view'
+        inside = sum(p.grad.data_ptr() == red._slot[p].data_ptr() for p in m2.parameters() if p.grad is not None)
+        assert inside == sum(p.grad is not None for p in m2.parameters())
+        ts2._update()
+        assert all(p.grad is None for p in m2.parameters())
+        ts1.step(imgs, tg)
+        for it, tol in ((41, 1e-4), (42, 1e-4)):
+            imgs, tg = batch(cfg, it)
+            l1, _ = ts1.step(imgs, tg)
+            l2, _ = ts2.step(imgs, tg)
+            close(l1, l2, what='loss', tol=tol)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=1e-3)
+        close(m1.model[-1].m[0].bias, m2.model[-1].m[0].bias, what='detect bias', tol=1e-3)
+    finally:
+        ops.GRAD_SLOTS.clear()
         dist.destroy_process_group()
