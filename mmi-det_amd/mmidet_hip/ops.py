@@ -118,7 +118,7 @@ def _side_stream(device):
     key = (device, 0 if SHARED_SIDE else _stream())
     s = _side_streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=device, priority=int(__import__("os").environ.get("MMIDET_SIDE_PRIORITY", "0")))
+        s = torch.cuda.Stream(device=device)   # (HIP stream priorities, two levels here, made no measurable difference)
         _side_streams[key] = s
     return s
 
