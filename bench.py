@@ -29,7 +29,10 @@ WORKLOADS = {
     'l_fourier': ('yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml', 1.0, 1.0, 128, 6, 16, 230.2),
     's_fourier': ('yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml', 0.33, 0.50, 64, 6, 16, 41.6),
     's_add': ('yolov5s_fusion_add_vedai.yaml', 0.33, 0.50, None, 9, 8, 32.5),
+    # BASELINE.json configs[4]: yolov5x (depth 1.33, width 1.25, FFM 160), 1280x1280, bs=8/GPU -- the HBM-heavy regime
+    'x_1280': ('yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml', 1.33, 1.25, 160, 6, 8, 1519.8),
 }
+IMAGE_SIZE = {'x_1280': 1280}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
@@ -263,13 +266,14 @@ def main():
     # (default) times three warm-up steps of each and keeps the faster one for the timed region.
     mode = 'eager' if args.no_graph else args.mode
     use_graph = False
-    ts = TrainStep(model, nc, 640, bs, world_size=world, accumulate=1, graph=False)
+    size = IMAGE_SIZE.get(args.workload, 640)
+    ts = TrainStep(model, nc, size, bs, world_size=world, accumulate=1, graph=False)
     if ddp:
         from mmidet_hip.ddp import GradReducer
         red = GradReducer(list(model.parameters()))
         red.broadcast_parameters(model)
         ts.reducer = red
-    imgs, tg = synth(bs, 640, nc, dev, 100 + rank)
+    imgs, tg = synth(bs, size, nc, dev, 100 + rank)
 
     timer = ConvTimer()
     if not args.no_roofline:
@@ -355,14 +359,15 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * bs * args.steps / dt
         out = {
-            'metric': 'paired RGB+IR img/s (train step, 640x640 yolov5l two-stream)', 'value': round(value, 3),
+            'metric': 'paired RGB+IR img/s (train step, %dx%d %s two-stream)' % (size, size, 'yolov5x' if args.workload == 'x_1280' else 'yolov5s' if args.workload.startswith('s_') else 'yolov5l'), 'value': round(value, 3),
             'unit': 'paired img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': {'l_fourier': 'yolov5l two-stream-fourier (default YAML, CEM+FFM+3xGPT), nc=6',
                                     's_fourier': 'yolov5s two-stream-fourier (GPT1_fourier[64]), nc=6',
-                                    's_add': 'yolov5s fusion_add (fusion modules off), nc=9'}[args.workload],
-                       'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,640,640)', 'dropout_p': args.dropout,
+                                    's_add': 'yolov5s fusion_add (fusion modules off), nc=9',
+                                    'x_1280': 'yolov5x two-stream-fourier (GPT1_fourier[160]), nc=6, 1280x1280'}[args.workload],
+                       'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,%d,%d)' % (size, size), 'dropout_p': args.dropout,
                        'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
                        'launch_mode_probe_ms': probes,
                        'launch_mode': ('eager, wgrad on a side stream' if not use_graph else 'whole-step hipGraph replay' if not ddp else

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   }
   __syncthreads();
   // out[r][hf-half of DK] = sum_j P[r][j] V[j][:]
-  constexpr int HV = (DK / 2) / 4 > 0 ? (DK / 2) / 4 : 1;  // float4s per half row (DK=4: both threads share, hf=1 idles)
-  constexpr bool SPLIT = DK >= 8;
+  constexpr bool SPLIT = DK % 8 == 0;  // both threads of a pair take half a row; else (DK = 4, 20) hf=0 takes it all
+  constexpr int HV = SPLIT ? (DK / 2) / 4 : 1;
   if (SPLIT || hf == 0) {
     f32x4 acc[SPLIT ? HV : DV];
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const int t = threadIdx.x, r = t >> 1, hf = t & 1;
   const int64_t base = (int64_t)b * T * ld + (int64_t)h * DK;
   constexpr int DV = DK / 4;
-  constexpr bool SPLIT = DK >= 8;
+  constexpr bool SPLIT = DK % 8 == 0;
   constexpr int HV = SPLIT ? (DK / 2) / 4 : DV;
   const int c0 = SPLIT ? hf * (DK / 2) : 0;
   auto stage = [&](const float* src) {
@@ -425,6 +425,10 @@ int attn_dispatch(int dk, F&& f) {
     case 32: return f(std::integral_constant<int, 32>());
     case 64: return f(std::integral_constant<int, 64>());
     case 128: return f(std::integral_constant<int, 128>());
+    case 20: return f(std::integral_constant<int, 20>());    // yolov5x widths 160/320/640/1280 over 8 heads
+    case 40: return f(std::integral_constant<int, 40>());
+    case 80: return f(std::integral_constant<int, 80>());
+    case 160: return f(std::integral_constant<int, 160>());
     default: return -1;
   }
 }
@@ -511,7 +515,7 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
     hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
     return 0;
   });
-  MMI_CHECK_ARG(rc == 0, "mmi_attention_fwd: head dim %d unsupported (4,8,16,32,64,128)", dk);
+  MMI_CHECK_ARG(rc == 0, "mmi_attention_fwd: head dim %d unsupported (4,8,16,20,32,40,64,80,128,160)", dk);
   MMI_CHECK_LAUNCH("mmi_attention_fwd");
   return MMI_OK;
 }
@@ -531,7 +535,7 @@ extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v,
                        seed, seed_dev, th, ik);
     return 0;
   });
-  MMI_CHECK_ARG(rc == 0, "mmi_attention_bwd: head dim %d unsupported (4,8,16,32,64,128)", dk);
+  MMI_CHECK_ARG(rc == 0, "mmi_attention_bwd: head dim %d unsupported (4,8,16,20,32,40,64,80,128,160)", dk);
   MMI_CHECK_LAUNCH("mmi_attention_bwd");
   return MMI_OK;
 }

@@ -75,7 +75,8 @@ def test_dropout_add():
     assert F2.dropout_add(big, None, 0.1, False) is big         # eval: identity
 
 
-@pytest.mark.parametrize('B,C,heads', [(2, 128, 8), (2, 256, 8), (3, 512, 8), (2, 1024, 8), (2, 32, 8)])
+@pytest.mark.parametrize('B,C,heads', [(2, 128, 8), (2, 256, 8), (3, 512, 8), (2, 1024, 8), (2, 32, 8),
+                                         (2, 160, 8), (2, 320, 8), (1, 640, 8), (1, 1280, 8)])   # yolov5x widths: dk 20..160
 def test_attention(B, C, heads):
     """softmax(QK^T/sqrt(dk))V per head (models/common.py:1206-1231), forward and backward, no dropout."""
     from mmidet_hip import fusion_ops as F2
