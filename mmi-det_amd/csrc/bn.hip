@@ -200,6 +200,44 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const
   }
 }
 
+// backward pass 1 for very narrow maps (C <= 8: the CEM's 3-channel output): one thread per row, all channels in
+// registers -- the 64-channel-lane layout above would leave 61 of 64 lanes idle
+__global__ __launch_bounds__(256) void bn_bwd_reduce_narrow_kernel(const float* __restrict__ y, int ldy,
+                                                                   const float* __restrict__ dout, int ldd,
+                                                                   const float* __restrict__ mi, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ partials,
+                                                                   int64_t rows, int C, int act, int64_t rows_per_part) {
+  __shared__ float red[2][8][256];
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_part, r1 = min(r0 + rows_per_part, rows);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s1[c] = s2[c] = 0.f;
+  for (int64_t r = r0 + t; r < r1; r += 256) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < C) {
+        const float xh = (y[r * ldy + c] - mi[c]) * mi[C + c];
+        const float dz = dout[r * ldd + c] * act_grad(xh * gamma[c] + beta[c], act);
+        s1[c] += dz;
+        s2[c] += dz * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    red[0][c][t] = s1[c];
+    red[1][c][t] = s2[c];
+  }
+  __syncthreads();
+  if (t < 2 * C) {                      // fixed-order fold: deterministic
+    const int sidx = t / C, c = t - sidx * C;
+    float acc = 0.f;
+    for (int i = 0; i < 256; ++i) acc += red[sidx][c][i];
+    partials[((int64_t)blockIdx.y * 2 + sidx) * C + c] = acc;
+  }
+}
+
 // partials -> dbeta (= sum dz), dgamma (= sum dz*xhat)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta) {
@@ -296,7 +334,14 @@ inline int ew_blocks(int64_t total) {
 // grid for a streaming kernel over rows x cv column groups; *fixed = the grid stride is a multiple of cv
 inline int ew_grid(int64_t rows, int cv, bool* fixed) {
   int b = ew_blocks(rows * cv);
-  if (cv > 256 && cv % 256 == 0) b = cdiv(b, cv / 256) * (cv / 256);
+  int g = cv, r = 256;  // gcd(cv, 256)
+  while (r) {
+    const int t = g % r;
+    g = r;
+    r = t;
+  }
+  const int m = cv / g;  // the grid stride 256*b is a multiple of cv iff b is a multiple of m (e.g. C=24: cv=6, m=3)
+  if (m <= 64) b = cdiv(b, m) * m;
   *fixed = ((int64_t)b * 256) % cv == 0;
   return b;
 }
@@ -374,7 +419,10 @@ extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout,
   const int64_t rpp = (rows + nparts - 1) / nparts;
   const dim3 grid(cdiv(C, 64), nparts);
   hipStream_t s = (hipStream_t)stream;
-  if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
+  if (C <= 8)
+    hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel, dim3(1, nparts), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma,
+                       beta, partials, rows, C, act, rpp);
+  else if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, beta, partials,
                        rows, C, act, rpp);
   else

@@ -82,65 +82,101 @@ __global__ __launch_bounds__(256) void smallconv_kernel(const float* __restrict_
 }
 
 // dW[co][tap][ci] = sum_pix dy[pix][co] * x[pix + tap - 1][ci]; each workgroup walks 16x16 pixel tiles with x (haloed)
-// and dy staged in LDS, every thread owning up to 3 of the COUT*9*CIN outputs; per-workgroup partials, summed afterwards.
+// and dy staged in LDS; per-workgroup partials, summed afterwards (rowsum_kernel).  One of the two channel counts is 3:
+// a thread owns one (tap, wide-channel) pair and the three narrow channels, so a pixel costs it one 16-byte LDS read of the
+// narrow operand (padded to 4 floats; the dy form is a wave-wide broadcast) plus one 4-byte read of the wide one for three
+// FMAs -- a third of the LDS instructions of the output-per-thread form, which was LDS-issue bound.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ dy, int ldy,
                                                               float* __restrict__ partials, int N, int H, int W) {
-  constexpr int NOUT = COUT * 9 * CIN, PER = (NOUT + 255) / 256;
-  __shared__ float xs[(TS + 2) * (TS + 2) * CIN];
-  __shared__ float ds[TS * TS * COUT];
+  static_assert((CIN == 3) != (COUT == 3), "one side has 3 channels");
+  constexpr bool XN = CIN == 3;                    // x is the narrow operand (conv2: 3 -> 24), else dy is (conv3: 24 -> 3)
+  constexpr int WIDE = XN ? COUT : CIN;            // 24
+  constexpr int NOUT = COUT * 9 * CIN;
+  constexpr int XE = XN ? 4 : CIN, DE = XN ? COUT : 4;   // floats per pixel in LDS
+  __shared__ __align__(16) float xs[(TS + 2) * (TS + 2) * XE];
+  __shared__ __align__(16) float ds[TS * TS * DE];
   const int t = threadIdx.x;
-  int o_co[PER], o_off[PER], o_ci[PER];
-  bool o_ok[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int o = t + 256 * j;
-    o_ok[j] = o < NOUT;
-    const int oo = o_ok[j] ? o : 0;
-    o_co[j] = oo / (9 * CIN);
-    const int r = oo - o_co[j] * 9 * CIN, tap = r / CIN;
-    o_ci[j] = r - tap * CIN;
-    o_off[j] = ((tap / 3) * (TS + 2) + tap % 3) * CIN + o_ci[j];  // xs offset of the tap relative to the pixel
-  }
-  float acc[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+  const bool owner = t < 9 * WIDE;
+  const int tap = owner ? t / WIDE : 0, wc = owner ? t - tap * WIDE : 0;
+  const int xoff = ((tap / 3) * (TS + 2) + tap % 3) * XE + (XN ? 0 : wc);   // of the tap, relative to the pixel
+  float acc[3] = {0.f, 0.f, 0.f};
   const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
   const int ntiles = tw * th * N;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tw * th), r = tile - n * tw * th;
     const int h0 = (r / tw) * TS, w0 = (r % tw) * TS;
     __syncthreads();
-    for (int e = t; e < (TS + 2) * (TS + 2) * CIN; e += 256) {
-      const int c = e % CIN, p = e / CIN;
+    for (int e = t; e < (TS + 2) * (TS + 2) * XE; e += 256) {
+      const int c = e % XE, p = e / XE;
       const int ih = h0 + p / (TS + 2) - 1, iw = w0 + p % (TS + 2) - 1;
-      xs[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? x[(((int64_t)n * H + ih) * W + iw) * ldx + c] : 0.f;
+      xs[e] = (c < CIN && ih >= 0 && iw >= 0 && ih < H && iw < W) ? x[(((int64_t)n * H + ih) * W + iw) * ldx + c] : 0.f;
     }
-    for (int e = t; e < TS * TS * COUT; e += 256) {
-      const int c = e % COUT, p = e / COUT;
+    for (int e = t; e < TS * TS * DE; e += 256) {
+      const int c = e % DE, p = e / DE;
       const int oh = h0 + p / TS, ow = w0 + p % TS;
-      ds[e] = (oh < H && ow < W) ? dy[(((int64_t)n * H + oh) * W + ow) * ldy + c] : 0.f;
+      ds[e] = (c < COUT && oh < H && ow < W) ? dy[(((int64_t)n * H + oh) * W + ow) * ldy + c] : 0.f;
     }
     __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < TS * TS; ++p) {
-      const int base = ((p / TS) * (TS + 2) + p % TS) * CIN;
+    if (owner) {
+      for (int pr = 0; pr < TS; ++pr) {
+        const float* xrow = xs + pr * (TS + 2) * XE + xoff;
+        const float* drow = ds + pr * TS * DE;
 #pragma unroll
-      for (int j = 0; j < PER; ++j) acc[j] += ds[p * COUT + o_co[j]] * xs[base + o_off[j]];
+        for (int pc = 0; pc < TS; ++pc) {
+          if (XN) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + pc * 4);
+            const float dv = drow[pc * DE + wc];
+            acc[0] += dv * xv[0];
+            acc[1] += dv * xv[1];
+            acc[2] += dv * xv[2];
+          } else {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(drow + pc * 4);
+            const float xv = xrow[pc * XE];
+            acc[0] += dv[0] * xv;
+            acc[1] += dv[1] * xv;
+            acc[2] += dv[2] * xv;
+          }
+        }
+      }
     }
   }
+  if (owner) {
 #pragma unroll
-  for (int j = 0; j < PER; ++j)
-    if (o_ok[j]) partials[(int64_t)blockIdx.x * NOUT + t + 256 * j] = acc[j];
+    for (int k = 0; k < 3; ++k) {
+      const int co = XN ? wc : k, ci = XN ? k : wc;
+      partials[(int64_t)blockIdx.x * NOUT + (co * 9 + tap) * CIN + ci] = acc[k];
+    }
+  }
 }
 
-__global__ void rowsum_kernel(const float* __restrict__ partials, int nparts, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)partials[(int64_t)p * n + i];
-  out[i] = (float)s;
+// out[i] = sum_p partials[p][i] in fp64, fixed order: 16 columns x 16 part-lanes per workgroup (a serial loop over 2048
+// parts per thread was 0.73 ms of pure load latency), lanes folded through LDS
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ partials, int nparts, int n,
+                                                      float* __restrict__ out) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i < n) {
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      s0 += (double)partials[(int64_t)p * n + i];
+      s1 += (double)partials[(int64_t)(p + 16) * n + i];
+      s2 += (double)partials[(int64_t)(p + 32) * n + i];
+      s3 += (double)partials[(int64_t)(p + 48) * n + i];
+    }
+    for (; p < nparts; p += 16) s0 += (double)partials[(int64_t)p * n + i];
+  }
+  red[pl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0 && i < n) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][cl];
+    out[i] = (float)s;
+  }
 }
 
 // ---- the stencil bank of EnhanceConv2d (models/common.py:838-882), index = out_channel % 8 ---------------------------
@@ -350,7 +386,7 @@ int mmi_smallconv_wgrad(const float* dy, const float* x, float* dw, void* worksp
   else
     hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel)");
-  hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, s, (const float*)part, blocks, nout, dw);
+  hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(nout, 16)), dim3(256), 0, s, (const float*)part, blocks, nout, dw);
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel reduce)");
   return MMI_OK;
 }

@@ -376,6 +376,9 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
       advance();
       const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
       const float* Bs = As + A_ELEMS;
+#ifdef MMI_SETPRIO
+      __builtin_amdgcn_s_setprio(MMI_SETPRIO);
+#endif
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
@@ -408,6 +411,9 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
+#ifdef MMI_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
       if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
       lstore(MMI_IGEMM_STAGES == 2 ? ((ks - ks0 + 1) & 1) : 0);
@@ -665,6 +671,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
     const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
+#ifdef MMI_SETPRIO
+    __builtin_amdgcn_s_setprio(MMI_SETPRIO);
+#endif
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {  // groups of four k-steps: all fragment reads up front, then 4*TM*TN MFMAs
       // a third of the next slab's loads ahead of each of the first three groups
@@ -690,6 +699,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
     }
+#ifdef MMI_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (MMI_WGRAD_STAGES == 1) __syncthreads();
     lstore(MMI_WGRAD_STAGES == 2 ? ((ks + 1) & 1) : 0);
