@@ -376,9 +376,6 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
       advance();
       const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
       const float* Bs = As + A_ELEMS;
-#ifdef MMI_SETPRIO
-      __builtin_amdgcn_s_setprio(MMI_SETPRIO);
-#endif
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
@@ -411,9 +408,6 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
-#ifdef MMI_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
       if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
       lstore(MMI_IGEMM_STAGES == 2 ? ((ks - ks0 + 1) & 1) : 0);
@@ -671,9 +665,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
     const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
-#ifdef MMI_SETPRIO
-    __builtin_amdgcn_s_setprio(MMI_SETPRIO);
-#endif
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {  // groups of four k-steps: all fragment reads up front, then 4*TM*TN MFMAs
       // a third of the next slab's loads ahead of each of the first three groups
@@ -699,9 +690,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
     }
-#ifdef MMI_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (MMI_WGRAD_STAGES == 1) __syncthreads();
     lstore(MMI_WGRAD_STAGES == 2 ? ((ks + 1) & 1) : 0);
@@ -825,9 +813,7 @@ int sk_occupancy(int bn) {
 // cost as much as 1024), so:
 //  * long K (>= 32 slabs per resident workgroup): stream-K over 128-wide tiles unless one workgroup per tile already
 //    fills the chip evenly (>= 93 % of the last "layer" of 256);
-//  * short K (1x1 convs, token projections; tools/sweep_tiles.py): one workgroup per tile; 128-wide tiles only when they
-//    fill the chip evenly (>= 88 %), else 64x64 tiles, whose finer grain and 5 resident workgroups per CU lose less to
-//    the last layer than they lose in per-tile efficiency (+10..16 % on the yolov5l 1x1 layers).
+//  * short K (1x1 convs, token projections; tools/sweep_tiles.py): one workgroup per tile, plan_tiles' shrink rule.
 template <bool DGRAD>
 FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
   FwdPlan f = plan_tiles(M, Ncol);
@@ -852,15 +838,10 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
     g.sk_grid = slots;
     return g;
   }
-  static const int mode = getenv("MMIDET_SHORTK_TILES") ? atoi(getenv("MMIDET_SHORTK_TILES")) : 0;
-  if (mode == 1) {  // experiment: finest balance (best standalone)
-    if (tiles >= slots && dp_eff >= 0.88) return g;
-    f.bm = f.bn = 64;
-    f.mtiles = cdiv(M, 64);
-    f.ntiles = cdiv(Ncol, 64);
-    return f;
-  }
-  if (mode == 2 && tiles >= 128) return g;  // experiment: always the most efficient tile, let the other lane fill the chip
+  // short K, or too little work per workgroup for stream-K: one workgroup per tile with the tile shrunk until the grid has
+  // two workgroups per CU (plan_tiles).  Finer 64x64 tiles win 10-16 % on the 1x1 layers stand-alone
+  // (profiles/r01_tile_sweep_short_k.txt) but nothing inside the step, where the other lane fills the tail; always taking the
+  // 128-wide tile loses 4 %.
   return f;
 }
 
