@@ -317,3 +317,17 @@ class GPT1_fourier(GPT):
         self.last_tokens = y.detach()
         a, b = F2.split_tokens(y)
         return FusedTokens(a, b, tuple(rgb.shape[1:3])), self.pattenLoss
+
+
+class RecContrastiveLoss(nn.Module):
+    """Parameter-free member of the reference's Model (`contrastive_loss_func`, yolo_test.py:94) that its forward never
+    calls.  Present so that checkpoints pickled by the reference -- which store the class by name -- unpickle against this
+    package (models/experimental.py).  Formula of the reference class (common.py:1431-1443): hinge on the positive pair
+    distance only."""
+
+    def __init__(self, margin=1.0):
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, anchor, positive, negative=None):
+        return torch.relu(torch.nn.functional.pairwise_distance(anchor, positive, 2) + self.margin).mean()

@@ -133,6 +133,18 @@ class Model(nn.Module):
         self._lanes, self._srcs = lanes, srcs
         self._ir_streams = {}
 
+    def __getstate__(self):
+        """Pickling (train.py:881-899 stores whole model objects) and deepcopy (ModelEMA): HIP stream handles stay behind."""
+        state = dict(self.__dict__)
+        state['_ir_streams'] = {}
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if '_lanes' not in state:            # an object written by the reference: same modules, none of the launch plan
+            self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
+            self._plan_lanes()
+
     def _ir_stream(self, device):
         s = self._ir_streams.get(device)
         if s is None:

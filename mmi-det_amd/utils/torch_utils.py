@@ -14,6 +14,12 @@ def is_parallel(model):
     return type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel) or hasattr(model, 'module')
 
 
+def intersect_dicts(da, db, exclude=()):
+    """Keys of da that db has with the same shape, minus `exclude` substrings (reference utils/torch_utils.py:139-141;
+    train.py:528 uses it to load a checkpoint into a re-configured model)."""
+    return {k: v for k, v in da.items() if k in db and not any(x in k for x in exclude) and v.shape == db[k].shape}
+
+
 def initialize_weights(model):
     """Parity-critical constants: every BatchNorm2d gets eps=1e-3, momentum=0.03."""
     for m in model.modules():

@@ -113,3 +113,27 @@ def test_nms_edge_cases():
     for a, b in zip(out, ref):
         assert torch.equal(a.cpu(), b)
         assert bool((a[1:, 4] <= a[:-1, 4]).all())                    # sorted by confidence
+
+
+def test_checkpoint_to_detections(tmp_path):
+    """detect_twostream.py:33,89-93 end to end: whole-object checkpoint -> attempt_load (fp32, fused, eval) -> forward ->
+    non_max_suppression; the detections equal those of the model that was saved (unfused) up to fp32 rounding."""
+    from copy import deepcopy
+    from models.experimental import attempt_load
+    from utils.general import non_max_suppression
+    m, _, x = build('fourier')
+    f = str(tmp_path / 'best.pt')
+    torch.save({'model': deepcopy(m).cpu(), 'ema': None}, f)
+    loaded = attempt_load(f, map_location=dev())
+    xd = x.to(dev())
+    with torch.no_grad():
+        z0 = m(xd[:, :3], xd[:, 3:])[0][0]
+        z1 = loaded(xd[:, :3], xd[:, 3:])[0][0]
+    close(z1, z0, tol=1e-4, what='decoded predictions after save / load / fuse')
+    d0 = non_max_suppression(z0, 0.2, 0.45)
+    d1 = non_max_suppression(z1, 0.2, 0.45)
+    assert [t.shape for t in d0] == [t.shape for t in d1]
+    for a, b in zip(d0, d1):
+        if a.numel():
+            close(a[:, :5], b[:, :5], tol=1e-3, what='boxes + confidences')
+            assert torch.equal(a[:, 5], b[:, 5])
