@@ -24,6 +24,10 @@ constexpr int BK = 32;
                             // measured +3 % over the double-buffered 2-waves/SIMD form); 2 = double buffer
 #endif
 constexpr int LDS_PAD = BK + 4;  // floats per [row][k] LDS row
+// which MFMA group (0..3) of the current slab issues prefetch load number i of the next slab
+#ifndef MMI_LOAD_SPREAD
+#define MMI_LOAD_SPREAD(i, g) ((i) % 3 == (g))
+#endif
 
 // Invalid lanes of the branch-free tile loaders read this instead of being masked afterwards: no select on the loaded
 // value, so hipcc does not have to wait for the load where it is issued (it would: `ok ? v : 0` forces vmcnt(0)).
@@ -382,10 +386,10 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
         // 1024 MFMA cycles then cover the tail of the load latency before the LDS stores below)
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-          if (i % 3 == g) load_a_row(i);
+          if (MMI_LOAD_SPREAD(i, g)) load_a_row(i);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-          if ((RA + i) % 3 == g) load_b_row(i);
+          if (MMI_LOAD_SPREAD(RA + i, g)) load_b_row(i);
         f32x4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -670,10 +674,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
       // a third of the next slab's loads ahead of each of the first three groups
 #pragma unroll
       for (int i = 0; i < ITA; ++i)
-        if (i % 3 == g) load_a_row(i);
+        if (MMI_LOAD_SPREAD(i, g)) load_a_row(i);
 #pragma unroll
       for (int i = 0; i < ITB; ++i)
-        if ((ITA + i) % 3 == g) load_b_row(i);
+        if (MMI_LOAD_SPREAD(ITA + i, g)) load_b_row(i);
       float a[4][TM], b[4][TN];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
