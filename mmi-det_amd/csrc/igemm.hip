@@ -18,7 +18,12 @@
 
 namespace {
 
-constexpr int BK = 32;
+#ifndef MMI_BK
+#define MMI_BK 32
+#endif
+constexpr int BK = MMI_BK;            // K-slab depth (32; 64 is an experiment: half the barriers per MFMA, two workgroups per CU)
+constexpr int KT = BK / 4;            // loader threads per tile row (one float4 each)
+constexpr int RPP = 256 / KT;         // tile rows covered by one pass of the 256 loader threads
 #ifndef MMI_IGEMM_STAGES
 #define MMI_IGEMM_STAGES 1  // LDS stages of the fwd/dgrad kernel: 1 = single buffer + register prefetch (3 waves/SIMD,
                             // measured +3 % over the double-buffered 2-waves/SIMD form); 2 = double buffer
@@ -202,13 +207,13 @@ struct SkRange {
 };
 
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK>
-__global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) void igemm_kernel(IgemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int RA = BM / 32;                       // A rows per loader thread
+  constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * LDS_PAD;
   constexpr int B_ELEMS = DGRAD ? BK * BN : BN * LDS_PAD;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
-  constexpr int RB = BN / 32;                       // fwd: B rows per loader thread
+  constexpr int RB = BN / RPP;                      // fwd: B rows per loader thread
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
   __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
   const bool par = !SK && DGRAD && p.par;
   const int nk = (tp.Ktot + BK - 1) / BK;
   const int ntaps = tp.Ktot / p.Kc;
-  const int kq = (t & 7) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
-  const int lrow = t >> 3;     // 0..31
+  const int kq = (t % KT) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
+  const int lrow = t / KT;      // 0..RPP-1
   const int l31 = lane & 31, lh = lane >> 5;
 
   // iteration range of this workgroup: data-parallel = the nk slabs of one tile; stream-K = an even share of everything
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
     RowInfo rows[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + lrow + 32 * i;
+      const int m = m0 + lrow + RPP * i;
       int orow = -1;
       if (m < Mc) {
         const int pq = Pc * Qc;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
         rows[i].base = -1;
         rows[i].ph = rows[i].qw = 0;
       }
-      if (par && (t & 7) == 0) rowmap[lrow + 32 * i] = orow;  // visible after the K loop's barriers
+      if (par && (t % KT) == 0) rowmap[lrow + RPP * i] = orow;  // visible after the K loop's barriers
     }
 
     f32x16 acc[TM][TN];
@@ -322,10 +327,10 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
     auto load_b_row = [&](int i) {
       if (!DGRAD) {
         if (!VEC) {
-          rb[i] = load_b_nk<VEC>(p, n0 + lrow + 32 * i, k0cur + kq);
+          rb[i] = load_b_nk<VEC>(p, n0 + lrow + RPP * i, k0cur + kq);
           return;
         }
-        const int n = n0 + lrow + 32 * i, k = k0cur + kq;
+        const int n = n0 + lrow + RPP * i, k = k0cur + kq;
         const bool ok = (n < p.Ncol) & (k < tp.Ktot);
         rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
       } else {
@@ -359,10 +364,10 @@ __global__ __launch_bounds__(256, MMI_IGEMM_STAGES == 1 ? 3 : 2) void igemm_kern
       float* As = smem + stage * STAGE;
       float* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_PAD + kq) = ra[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDS_PAD + kq) = ra[i];
       if (!DGRAD) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * i) * LDS_PAD + kq) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * LDS_PAD + kq) = rb[i];
       } else {
 #pragma unroll
         for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[i];
@@ -524,7 +529,7 @@ struct WgradP {
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
 
 template <int BM, int BN, bool VEC>
-__global__ __launch_bounds__(256, 3) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
