@@ -244,11 +244,12 @@ int mmi_sgd_ema_step(const void* recs_dev, const void* chunks_dev, int nchunks, 
 int mmi_detect_decode(const float* x, float* z, int B, int na, int ny, int nx, int no, int64_t total_rows,
                       int64_t row_offset, float stride, const float* anchor_px, void* stream);
 /* non_max_suppression (utils/general.py:486-580; NMS proper = torchvision.ops.nms semantics): pred (B,R,nc+5) decoded
- * rows; class_mask bit j = class j allowed (general.py:549-550 `classes`; all ones = no filter); max_wh 4096 is the
+ * rows; class_allow: device array of nc bytes, non-zero = class kept (general.py:549-550 `classes`), NULL = no filter;
+ * max_wh 4096 is the
  * reference's class offset; out (B,max_det,6) = [x1,y1,x2,y2,conf,cls] by decreasing confidence, nout[B] rows valid.
  * Every candidate takes part (the reference first cuts to its 30 000 best). */
 size_t mmi_nms_workspace(int B, int64_t R, int nc, int multi_label);
-int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float iou_thres, uint64_t class_mask, int agnostic,
+int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float iou_thres, const uint8_t* class_allow, int agnostic,
             int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes, float* out, int* nout,
             void* stream);
 

@@ -48,7 +48,7 @@ struct NmsBuf {
 };
 
 __global__ void nms_candidates_kernel(const float* __restrict__ pred, int B, int64_t R, int nc, float conf_thres,
-                                      int multi_label, uint64_t class_mask, int64_t cap, NmsBuf w) {
+                                      int multi_label, const uint8_t* __restrict__ class_allow, int64_t cap, NmsBuf w) {
   const int64_t total = (int64_t)B * R;
   const int no = nc + 5;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -70,7 +70,7 @@ __global__ void nms_candidates_kernel(const float* __restrict__ pred, int B, int
     if (multi_label) {
       for (int j = 0; j < nc; ++j) {
         const float conf = p[5 + j] * obj;
-        if (conf > conf_thres && ((class_mask >> j) & 1)) emit(j, conf);
+        if (conf > conf_thres && (class_allow == nullptr || class_allow[j])) emit(j, conf);
       }
     } else {
       int bj = 0;
@@ -79,7 +79,7 @@ __global__ void nms_candidates_kernel(const float* __restrict__ pred, int B, int
         const float conf = p[5 + j] * obj;
         if (conf > best) best = conf, bj = j;                  // first maximum, as torch.max
       }
-      if (best > conf_thres && ((class_mask >> bj) & 1)) emit(bj, best);
+      if (best > conf_thres && (class_allow == nullptr || class_allow[bj])) emit(bj, best);
     }
   }
 }
@@ -170,10 +170,10 @@ extern "C" size_t mmi_nms_workspace(int B, int64_t R, int nc, int multi_label) {
   return (size_t)B * cap * (4 + 1 + 1 + 1) * 4 + (size_t)B * 4 + 64;
 }
 
-extern "C" int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float iou_thres, uint64_t class_mask,
-                       int agnostic, int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes,
+extern "C" int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float iou_thres,
+                       const uint8_t* class_allow, int agnostic, int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes,
                        float* out, int* nout, void* stream) {
-  MMI_CHECK_ARG(pred && out && nout && workspace && B > 0 && R > 0 && nc > 0 && nc <= 64 && max_det > 0, "mmi_nms: bad arguments");
+  MMI_CHECK_ARG(pred && out && nout && workspace && B > 0 && R > 0 && nc > 0 && max_det > 0, "mmi_nms: bad arguments");
   MMI_CHECK_ARG((int64_t)R * nc < (1LL << 31), "mmi_nms: too many (row, class) pairs");
   if (workspace_bytes < mmi_nms_workspace(B, R, nc, multi_label)) {
     mmi_set_error("mmi_nms: workspace too small (%zu < %zu)", workspace_bytes, mmi_nms_workspace(B, R, nc, multi_label));
@@ -198,7 +198,7 @@ extern "C" int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_t
     return MMI_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(nms_blocks((int64_t)B * R)), dim3(256), 0, s, pred, B, R, nc, conf_thres,
-                     multi_label, class_mask, cap, w);
+                     multi_label, class_allow, cap, w);
   MMI_CHECK_LAUNCH("mmi_nms(candidates)");
   hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(1024), 0, s, w, cap, iou_thres, agnostic ? 0.0f : max_wh, max_det, out,
                      nout);

@@ -36,7 +36,7 @@ _SIGS = {
     'mmi_conv_bias_act_fwd': (c_int, [P, P, P, P, c_int, c_int, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_detect_decode': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_float, P, P]),
     'mmi_nms_workspace': (c_size_t, [c_int, c_int64, c_int, c_int]),
-    'mmi_nms': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_int, c_float, P, c_size_t, P, P,
+    'mmi_nms': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, c_int, c_int, c_int, c_float, P, c_size_t, P, P,
                         P]),
     'mmi_conv_dgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_dgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),

@@ -337,8 +337,9 @@ def detect_decode(levels, strides, anchor_grid, no):
     return z
 
 
-def nms(pred, conf_thres, iou_thres, class_mask, agnostic, multi_label, max_det=300, max_wh=4096.0):
-    """utils/general.py:486-580 on the device; returns (out (B,max_det,6), nout (B,) int32)."""
+def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det=300, max_wh=4096.0):
+    """utils/general.py:486-580 on the device; classes = iterable of kept class ids or None; returns
+    (out (B,max_det,6), nout (B,) int32)."""
     pred = pred.contiguous()
     assert pred.dtype == torch.float32 and pred.is_cuda and pred.dim() == 3
     b, r, no = pred.shape
@@ -346,8 +347,13 @@ def nms(pred, conf_thres, iou_thres, class_mask, agnostic, multi_label, max_det=
     ws = torch.empty(nb, dtype=torch.uint8, device=pred.device)
     out = torch.zeros((b, max_det, 6), dtype=torch.float32, device=pred.device)
     nout = torch.zeros(b, dtype=torch.int32, device=pred.device)
-    lib.nms(pred.data_ptr(), b, r, no - 5, conf_thres, iou_thres, class_mask, int(agnostic), int(multi_label), max_det,
-            max_wh, ws.data_ptr(), nb, out.data_ptr(), nout.data_ptr(), _stream())
+    allow = None
+    if classes is not None:
+        allow = torch.zeros(no - 5, dtype=torch.uint8)
+        allow[[int(c) for c in classes if 0 <= int(c) < no - 5]] = 1
+        allow = allow.to(pred.device)
+    lib.nms(pred.data_ptr(), b, r, no - 5, conf_thres, iou_thres, allow.data_ptr() if allow is not None else None,
+            int(agnostic), int(multi_label), max_det, max_wh, ws.data_ptr(), nb, out.data_ptr(), nout.data_ptr(), _stream())
     return out, nout
 
 

@@ -59,13 +59,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     from mmidet_hip import ops
     if labels:
         raise NotImplementedError('a-priori labels (autolabelling, general.py:519-526) are outside the detection path')
-    nc = prediction.shape[2] - 5
-    assert 0 < nc <= 64, 'class filter is a 64-bit mask'
-    mask = (1 << 64) - 1
-    if classes is not None:
-        mask = 0
-        for c in classes:
-            mask |= 1 << int(c)
-    out, nout = ops.nms(prediction.float(), float(conf_thres), float(iou_thres), mask, bool(agnostic), bool(multi_label))
+    out, nout = ops.nms(prediction.float(), float(conf_thres), float(iou_thres), classes, bool(agnostic), bool(multi_label))
     counts = nout.tolist()
     return [out[i, :n] for i, n in enumerate(counts)]

@@ -86,6 +86,18 @@ def test_nms_matches_oracle_and_reference_fixture():
             assert np.array_equal(t.cpu().numpy(), ref), (name, i)
 
 
+def test_nms_eighty_classes_with_filter():
+    """nc = 80 (the reference's COCO default): no 64-class limit, class filter as a device byte array."""
+    from oracle import ref_nms
+    from utils.general import non_max_suppression
+    pred = ref_nms.synth_predictions(21, bs=2, rows=200, nc=80)
+    for kw in (dict(), dict(classes=[3, 70, 79]), dict(multi_label=True, conf_thres=0.5)):
+        out = non_max_suppression(pred.to(dev()), **kw)
+        ref = ref_nms.non_max_suppression(pred, **kw)
+        for a, b in zip(out, ref):
+            assert torch.equal(a.cpu(), b), kw
+
+
 def test_nms_edge_cases():
     from oracle import ref_nms
     from utils.general import non_max_suppression
