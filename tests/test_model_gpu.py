@@ -239,3 +239,31 @@ def test_yolov5l_640_train_step_matches_oracle():
         assert rel_err(p.grad, r) < 2e-3, (n, rel_err(p.grad, r))
         checked += 1
     assert checked >= 12
+
+
+@pytest.mark.parametrize('bs', [1, 3])
+def test_odd_batch_sizes_match_oracle(bs):
+    """B=1 (the Contrast Bridge has no neighbour pair: its value is NaN in the reference too, and it feeds nothing) and an
+    odd batch: forward, loss and a gradient against the oracle."""
+    from oracle import portable_init
+    from oracle.ref_loss import ComputeLoss as OLoss
+    from utils.loss import ComputeLoss
+    m, o, cfg = build_pair('fourier', 128)
+    imgs, targets = portable_init.synth_batch(bs, 128, cfg['nc'], per_image=4, seed=5)
+    x = imgs.float() / 255
+    m.train()
+    o.train()
+    po, co = o(x[:, :3], x[:, 3:])
+    lo, io = OLoss(o)(po, targets, co.reshape(-1))
+    lo.backward()
+    xd = x.to(dev())
+    pg, cg = m(xd[:, :3], xd[:, 3:])
+    lg, ig = ComputeLoss(m)(pg, targets.to(dev()), cg.reshape(-1))
+    lg.backward()
+    assert torch.isfinite(lg).all()
+    for i in range(3):
+        close(pg[i], po[i], what='pred%d' % i)
+    close(lg, lo, what='loss', tol=1e-4)
+    close(ig, io, what='items', tol=1e-4)
+    w, wo = m.model[1].conv.weight, o.model[1].conv.weight
+    close(w.grad, wo.grad, what='dW(model.1.conv)', tol=2e-3)
