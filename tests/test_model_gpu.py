@@ -267,3 +267,32 @@ def test_odd_batch_sizes_match_oracle(bs):
     close(ig, io, what='items', tol=1e-4)
     w, wo = m.model[1].conv.weight, o.model[1].conv.weight
     close(w.grad, wo.grad, what='dW(model.1.conv)', tol=2e-3)
+
+
+def test_rectangular_image_matches_oracle():
+    """Non-square input (96 x 160, both multiples of 32 as general.py:140-146 enforces): adaptive 8x8 pooling windows that
+    are neither uniform nor equal along the two axes, rectangular grids in the loss."""
+    from oracle.ref_loss import ComputeLoss as OLoss
+    from oracle.portable_init import _u01
+    from utils.loss import ComputeLoss
+    import numpy as np
+    m, o, cfg = build_pair('fourier', 160)
+    bs, h, w = 2, 96, 160
+    x = torch.from_numpy(_u01('rect', bs * 6 * h * w).astype(np.float32)).reshape(bs, 6, h, w)
+    targets = torch.tensor([[0, 1, .3, .4, .2, .3], [0, 3, .7, .6, .1, .2], [1, 2, .5, .5, .4, .3], [1, 0, .2, .8, .15, .1]])
+    m.train()
+    o.train()
+    po, co = o(x[:, :3], x[:, 3:])
+    lo, io = OLoss(o)(po, targets, co.reshape(-1))
+    lo.backward()
+    xd = x.to(dev())
+    pg, cg = m(xd[:, :3], xd[:, 3:])
+    lg, ig = ComputeLoss(m)(pg, targets.to(dev()), cg.reshape(-1))
+    lg.backward()
+    for i in range(3):
+        assert tuple(pg[i].shape) == tuple(po[i].shape)
+        close(pg[i], po[i], what='pred%d' % i)
+    close(lg, lo, what='loss', tol=1e-4)
+    close(cg, co, what='Combine_loss', tol=1e-4)
+    close(m.model[1].conv.weight.grad, o.model[1].conv.weight.grad, what='dW(model.1.conv)', tol=2e-3)
+    close(m.model[6].conv1.weight.grad, o.model[6].conv1.weight.grad, what='dW(FFM conv1)', tol=2e-3)
