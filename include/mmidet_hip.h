@@ -58,6 +58,10 @@ int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
  * shape with >= 2 K slabs (lets small test shapes take the schedule), n < 0 = schedule off.  Returns the old value.
  * Changes what the *_workspace() and row_blocks() queries answer: set it before planning a call, not between. */
 int mmi_set_streamk_slots(int slots);
+/* Arithmetic of the forward-layout GEMMs (conv / linear forward): 0 (default) = exact fp32 products on
+ * v_mfma_f32_32x32x2_f32; 1 (opt-in) = each fp32 operand split into two bf16 terms, product = hi*hi + hi*lo + lo*hi on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error <= 2^-16).  dgrad / wgrad stay fp32. */
+int mmi_set_gemm_precision(int mode);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
 int mmi_set_tile_override(int bm, int bn);

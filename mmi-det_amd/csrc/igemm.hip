@@ -206,12 +206,42 @@ struct SkRange {
   }
 };
 
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK>
+// PREC = 0: exact fp32 products (v_mfma_f32_32x32x2_f32).  PREC = 1 (opt-in, forward-layout operands only): every fp32
+// operand is split into two bf16 terms when it is staged into LDS, x = hi + lo with |x - hi - lo| <= 2^-17 |x|, and a product
+// is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 instructions of 8 passes per 16 k instead
+// of 8 instructions of 16 passes, relative error of a product <= 2^-16 (the dropped lo*lo term is 2^-18).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// eight consecutive k (rows p, p+1, ... p+7 of a k-major bf16 image) of this lane's column via two ds_read_b64_tr_b16
+__device__ __forceinline__ bf16x8 tr_read8(const char* p, int row_bytes) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * row_bytes));
+  const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (__bf16)v[i];
+    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  }
+}
+
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) void igemm_kernel(IgemmP p) {
+  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 form exists for the vector loaders only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * LDS_PAD;
-  constexpr int B_ELEMS = DGRAD ? BK * BN : BN * LDS_PAD;
+  // split-bf16 dgrad: the weight tile stays k-major ([k][n], as it comes from OHWI memory) in two bf16 planes whose rows are
+  // padded by 64 B (conflict-free ds_read_b64_tr_b16: the MFMA B operand is fetched with the hardware transpose read)
+  constexpr int B_RSB = BN * 2 + 64;                                  // bytes per k row of one plane
+  constexpr int B_ELEMS = DGRAD ? (PREC == 1 ? 2 * BK * B_RSB / 4 : BK * BN) : BN * LDS_PAD;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   constexpr int RB = BN / RPP;                      // fwd: B rows per loader thread
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
@@ -363,6 +393,38 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
     auto lstore = [&](int stage) {
       float* As = smem + stage * STAGE;
       float* Bs = As + A_ELEMS;
+      if constexpr (PREC == 1) {
+        // row record = 36 floats as in the fp32 form: 32 bf16 "hi" (64 B) | 32 bf16 "lo" (64 B) | 16 B pad
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          bf16x4 hi, lo;
+          split_bf16(ra[i], hi, lo);
+          __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPP * i) * LDS_PAD);
+          *reinterpret_cast<bf16x4*>(row + kq) = hi;
+          *reinterpret_cast<bf16x4*>(row + 32 + kq) = lo;
+        }
+        if constexpr (!DGRAD) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            bf16x4 hi, lo;
+            split_bf16(rb[i], hi, lo);
+            __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrow + RPP * i) * LDS_PAD);
+            *reinterpret_cast<bf16x4*>(row + kq) = hi;
+            *reinterpret_cast<bf16x4*>(row + 32 + kq) = lo;
+          }
+        } else {
+          char* base = reinterpret_cast<char*>(Bs);
+#pragma unroll
+          for (int i = 0; i < KB_IT; ++i) {
+            bf16x4 hi, lo;
+            split_bf16(rb[i], hi, lo);
+            char* dst = base + (t / VPR + RPI * i) * B_RSB + (t % VPR) * 8;
+            *reinterpret_cast<bf16x4*>(dst) = hi;
+            *reinterpret_cast<bf16x4*>(dst + BK * B_RSB) = lo;
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDS_PAD + kq) = ra[i];
       if (!DGRAD) {
@@ -385,6 +447,51 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
       advance();
       const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
       const float* Bs = As + A_ELEMS;
+      if constexpr (PREC == 1) {
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+          // the next slab's global loads: two thirds ahead of the first 16-k block, the rest ahead of the second
+#pragma unroll
+          for (int i = 0; i < RA; ++i)
+            if (kb == 0 ? (i % 3 != 2) : (i % 3 == 2)) load_a_row(i);
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+            if (kb == 0 ? ((RA + i) % 3 != 2) : ((RA + i) % 3 == 2)) load_b_row(i);
+          bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float* row = As + (wm * WM + i * 32 + l31) * LDS_PAD + kb * 8 + lh * 4;   // float index = byte offset / 4
+            ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row));
+            al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16));
+          }
+          if constexpr (!DGRAD) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float* row = Bs + (wn * WN + j * 32 + l31) * LDS_PAD + kb * 8 + lh * 4;
+              bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row));
+              bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16));
+            }
+          } else {
+            // transposed read: per 16-lane group a block of 4 k-rows x 16 columns; lane 4q+p supplies row q, columns 4p..4p+3
+            // and receives column (lane % 16) of the four rows; two reads = the 8 consecutive k of this lane's column
+            const int q = (lane & 15) >> 2, pp = lane & 3, m0 = ((lane >> 4) & 1) * 16;
+            const char* base = reinterpret_cast<const char*>(Bs) + (kb * 16 + lh * 8 + q) * B_RSB + (wn * WN + m0 + 4 * pp) * 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              bh[j] = tr_read8(base + j * 64, B_RSB);
+              bl[j] = tr_read8(base + j * 64 + BK * B_RSB, B_RSB);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         // a third of the next slab's global loads ahead of each of the first three MFMA groups (the fourth group's
@@ -416,6 +523,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
       if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
@@ -528,12 +636,17 @@ struct WgradP {
 // the 64x64 tile of the tall-skinny 1x1 layers, whose short MFMA phase cannot hide a second barrier per slab.
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) {
+  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 form exists for the vector loaders only");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
-  constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN, STAGE = A_ELEMS + B_ELEMS;
+  // split-bf16 (PREC = 1): both tiles stay k-major in two bf16 planes with rows padded by 64 B; the MFMA operands (8
+  // consecutive pixels of one channel) come out of ds_read_b64_tr_b16
+  constexpr int A_RSB = BM * 2 + 64, B_RSB = BN * 2 + 64;
+  constexpr int A_ELEMS = PREC == 1 ? 2 * BK * A_RSB / 4 : BK * BM, B_ELEMS = PREC == 1 ? 2 * BK * B_RSB / 4 : BK * BN;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
   __shared__ __align__(16) float smem[MMI_WGRAD_STAGES * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -654,6 +767,28 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
   auto lstore = [&](int stage) {
     float* As = smem + stage * STAGE;
     float* Bs = As + A_ELEMS;
+    if constexpr (PREC == 1) {
+      char* ab = reinterpret_cast<char*>(As);
+      char* bb = reinterpret_cast<char*>(Bs);
+#pragma unroll
+      for (int i = 0; i < ITA; ++i) {
+        bf16x4 hi, lo;
+        split_bf16(ra[i], hi, lo);
+        char* dst = ab + (akr + RPA * i) * A_RSB + (t % VA) * 8;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + BK * A_RSB) = lo;
+        if (want_bias) bsum += ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < ITB; ++i) {
+        bf16x4 hi, lo;
+        split_bf16(rb[i], hi, lo);
+        char* dst = bb + (bkr + RPB * i) * B_RSB + (t % VB) * 8;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + BK * B_RSB) = lo;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < ITA; ++i) {
       *reinterpret_cast<f32x4*>(As + (akr + RPA * i) * BM + (t % VA) * 4) = ra[i];
@@ -674,6 +809,39 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
     const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
+    if constexpr (PREC == 1) {
+      const int q = (lane & 15) >> 2, pp = lane & 3, m0 = ((lane >> 4) & 1) * 16;
+#pragma unroll
+      for (int kb = 0; kb < BK / 16; ++kb) {
+#pragma unroll
+        for (int i = 0; i < ITA; ++i)
+          if (kb == 0 ? (i % 3 != 2) : (i % 3 == 2)) load_a_row(i);
+#pragma unroll
+        for (int i = 0; i < ITB; ++i)
+          if (kb == 0 ? ((ITA + i) % 3 != 2) : ((ITA + i) % 3 == 2)) load_b_row(i);
+        const char* ab = reinterpret_cast<const char*>(As) + (kb * 16 + lh * 8 + q) * A_RSB + (wm * WM + m0 + 4 * pp) * 2;
+        const char* bb = reinterpret_cast<const char*>(Bs) + (kb * 16 + lh * 8 + q) * B_RSB + (wn * WN + m0 + 4 * pp) * 2;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = tr_read8(ab + i * 64, A_RSB);
+          al[i] = tr_read8(ab + i * 64 + BK * A_RSB, A_RSB);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = tr_read8(bb + j * 64, B_RSB);
+          bl[j] = tr_read8(bb + j * 64 + BK * B_RSB, B_RSB);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {  // groups of four k-steps: all fragment reads up front, then 4*TM*TN MFMAs
       // a third of the next slab's loads ahead of each of the first three groups
@@ -698,6 +866,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (MMI_WGRAD_STAGES == 1) __syncthreads();
@@ -763,6 +932,7 @@ struct FwdPlan {
   int bm, bn, mtiles, ntiles;
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
+int g_gemm_prec = 0;  // mmi_set_gemm_precision: 0 = exact fp32 MFMA, 1 = split-bf16 products for forward-layout GEMMs
 int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
 FwdPlan plan_tiles(int64_t M, int Ncol) {
   FwdPlan f;
@@ -878,6 +1048,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     p.sk_count = (int*)workspace;
     p.sk_slots = (float*)((char*)workspace + SK_COUNTER_BYTES);
     const dim3 grid(f.sk_grid), block(256);
+    if (g_gemm_prec == 1) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
     if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true>), grid, block, 0, s, p);
     MMI_CHECK_LAUNCH(who);
@@ -886,6 +1062,15 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false>), grid, block, 0, s, p)
+  if (vec && g_gemm_prec == 1) {
+#define LAUNCH_B3(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1>), grid, block, 0, s, p)
+    if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
+    else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
+    else LAUNCH_B3(64, 64);
+#undef LAUNCH_B3
+    MMI_CHECK_LAUNCH(who);
+    return MMI_OK;
+  }
   if (!vec) {
     if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
     else LAUNCH(64, 64, false);
@@ -925,6 +1110,12 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int mmi_set_gemm_precision(int mode) {
+  MMI_CHECK_ARG(mode == 0 || mode == 1, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = split-bf16 products)", mode);
+  g_gemm_prec = mode;
+  return MMI_OK;
+}
 
 extern "C" int mmi_set_tile_override(int bm, int bn) {
   const bool ok = (bm == 0 && bn == 0) || (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64);
@@ -1124,7 +1315,14 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
-  if (!g.vec) LAUNCHW(64, 64, false);
+  if (g.vec && g_gemm_prec == 1) {
+#define LAUNCHW3(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p)
+    if (g.bm == 128 && g.bn == 128) LAUNCHW3(128, 128);
+    else if (g.bm == 128) LAUNCHW3(128, 64);
+    else if (g.bn == 128) LAUNCHW3(64, 128);
+    else LAUNCHW3(64, 64);
+#undef LAUNCHW3
+  } else if (!g.vec) LAUNCHW(64, 64, false);
   else if (g.bm == 128 && g.bn == 128) LAUNCHW(128, 128, true);
   else if (g.bm == 128) LAUNCHW(128, 64, true);
   else if (g.bn == 128) LAUNCHW(64, 128, true);

@@ -31,6 +31,7 @@ _SIGS = {
     'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
     'mmi_set_streamk_slots': (c_int, [c_int]),
     'mmi_set_tile_override': (c_int, [c_int, c_int]),
+    'mmi_set_gemm_precision': (c_int, [c_int]),
     'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_fwd': (c_int, [P, P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_bias_act_fwd': (c_int, [P, P, P, P, c_int, c_int, P, P, c_size_t, POINTER(ConvDesc), P]),

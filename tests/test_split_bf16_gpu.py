@@ -1,0 +1,127 @@
+"""GPU parity of the OPT-IN split-bf16 GEMM arithmetic (mmi_set_gemm_precision(1), csrc/igemm.hip PREC = 1): every fp32
+product formed as hi*hi + hi*lo + lo*hi of bf16 halves on v_mfma_f32_32x32x16_bf16, fp32 accumulation.  Same checks and
+the same tolerances as the default fp32-MFMA path for every op and for the model's forward and loss; the whole-step
+parameter gradients get the looser bound they need (see test_train_step_split_bf16_matches_oracle)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_ops_gpu import CONV_CASES, close, cl, dev, nchw, nhwc, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def split_bf16():
+    from mmidet_hip import lib
+    lib.set_gemm_precision(1)
+    yield lib
+    lib.set_gemm_precision(0)
+    lib.set_streamk_slots(0)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd_split_bf16(case, split_bf16):
+    from mmidet_hip import ops
+    N, H, W, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, s, k // 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    d = dev()
+    xg, wg, bg = nhwc(x).to(d).requires_grad_(), cl(w).to(d).requires_grad_(), b.to(d).requires_grad_()
+    yg = ops.conv_bias(xg, wg, bg, s)
+    yg.backward(nhwc(gy).to(d))
+    close(nchw(yg), yr, what='y')
+    close(nchw(xg.grad), xr.grad, what='dx')
+    close(wg.grad, wr.grad, what='dw')
+    close(bg.grad, br.grad, what='db')
+
+
+@pytest.mark.parametrize('slots', [5, 24])
+def test_streamk_split_bf16(slots, split_bf16):
+    """The stream-K schedule (partial tiles folded by the last contributor) with the split-bf16 inner product."""
+    from mmidet_hip import ops
+    split_bf16.set_streamk_slots(slots)
+    g = torch.Generator().manual_seed(slots)
+    x = torch.randn(4, 128, 40, 40, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / (128 * 9) ** 0.5
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    d = dev()
+    xg, wg = nhwc(x).to(d).requires_grad_(), cl(w).to(d).requires_grad_()
+    yg = ops.conv_bias(xg, wg, None, 1)
+    yg.backward(nhwc(gy).to(d))
+    close(nchw(yg), yr, what='y')
+    close(nchw(xg.grad), xr.grad, what='dx')
+    close(wg.grad, wr.grad, what='dw')
+
+
+@pytest.mark.parametrize('kind', ['add', 'fourier'])
+def test_train_step_split_bf16_matches_oracle(kind, split_bf16):
+    from oracle import portable_init
+    from oracle.ref_loss import ComputeLoss as OLoss
+    from test_model_gpu import build_pair
+    from utils.loss import ComputeLoss
+    m, o, cfg = build_pair(kind, 128)
+    imgs, targets = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=2)
+    x = imgs.float() / 255
+    m.train()
+    o.train()
+    po, co = o(x[:, :3], x[:, 3:])
+    lo, io = OLoss(o)(po, targets, co.reshape(-1))
+    lo.backward()
+    xd = x.to(dev())
+    pg, cg = m(xd[:, :3], xd[:, 3:])
+    lg, ig = ComputeLoss(m)(pg, targets.to(dev()), cg.reshape(-1))
+    lg.backward()
+    for i in range(3):
+        close(pg[i], po[i], what='pred%d' % i)
+    close(lg, lo, what='loss', tol=1e-4)
+    close(ig, io, what='items', tol=1e-4)
+    # Gradients are where the split arithmetic shows: a GEMM result is off by ~5e-6, predictions by ~3e-5, but ~150 layers of
+    # backward (BatchNorm's mean-subtraction cancels leading digits) amplify that to ~1e-3 per parameter gradient (fp32 MFMA
+    # path: 5e-5, tools/b3_diag.py).  That is why the mode is opt-in and not the benchmarked default.
+    og = dict(o.named_parameters())
+    errs = sorted(rel_err(p.grad, og[n].grad) for n, p in m.named_parameters()
+                  if og[n].grad is not None and p.grad is not None and float(og[n].grad.norm()) > 1e-5)
+    assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 2e-2, (errs[len(errs) // 2], errs[-1])
+
+
+@pytest.mark.parametrize('shape', [(16, 80, 80, 128, 128, 3, 1), (16, 160, 160, 128, 256, 3, 2), (16, 40, 40, 512, 256, 1, 1)])
+def test_full_size_layers_split_bf16_vs_fp32_mfma(shape):
+    """BASELINE-size layers: forward, dgrad and wgrad of the split form against the exact fp32-MFMA kernels.  A product
+    carries <= 2^-16 relative error and the errors of a K-long sum average out: 2e-5 is a loose bound (measured 4.5e-6)."""
+    from mmidet_hip import lib, ops
+    N, H, W, Cin, Cout, k, s = shape
+    d = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(d)
+    desc = ops._desc((N, H, W, Cin), Cout, k, s, Cin, Cout)
+    dy = torch.randn(N, desc.Ho, desc.Wo, Cout, generator=g).to(d)
+    res = {}
+    for mode in (0, 1):
+        lib.set_gemm_precision(mode)
+        try:
+            y = torch.empty(N, desc.Ho, desc.Wo, Cout, device=d)
+            dx = torch.empty_like(x)
+            dw = torch.empty_like(w)
+            nb = lib.conv_wgrad_workspace(desc)
+            ws = torch.empty(max(nb // 4, 1), device=d)
+            ops.conv_fwd(x, w, None, y, None, desc, st)
+            ops.conv_dgrad(dy, w, dx, desc, st)
+            lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
+            torch.cuda.synchronize()
+            res[mode] = (y, dx, dw)
+        finally:
+            lib.set_gemm_precision(0)
+    for name, a, b in zip(('y', 'dx', 'dw'), res[1], res[0]):
+        close(a, b, tol=2e-5, what=name + ' split-bf16 vs fp32 MFMA')
