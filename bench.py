@@ -223,9 +223,11 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-gemm', default=None, help='write the per-shape GEMM time table of the roofline pass here')
     ap.add_argument('--ddp', action='store_true', help='run the data-parallel code path even on one GPU (world size 1)')
-    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'split_bf16'],
-                    help='arithmetic of the conv/linear GEMMs in the TIMED region: exact fp32 MFMA (default, the headline) or '
-                         'the opt-in split-bf16 products (3 bf16 MFMAs per fp32 product, fp32 accumulate, ~5e-6 relative)')
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x6', 'bf16x3'],
+                    help='arithmetic of the conv/linear GEMMs in the TIMED region.  fp32 (default, the headline): exact fp32 '
+                         'products on v_mfma_f32_32x32x2_f32.  bf16x6: every operand split into three bf16 terms, six bf16 MFMA '
+                         'products of total order <= 2, fp32 accumulation -- fp32-level accuracy (GEMM 3e-7..1e-6 vs the fp32 '
+                         'kernels, gradients as the fp32 path).  bf16x3: two terms, three products (GEMM 4.5e-6, gradients ~1e-3)')
     ap.add_argument('--no-split-probe', action='store_true', help='skip the extra split-bf16 measurement after the timed region')
     ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
@@ -295,7 +297,7 @@ def main():
             print('[bench %.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     from mmidet_hip import lib as _lib
-    _lib.set_gemm_precision(1 if args.gemm == 'split_bf16' else 0)
+    _lib.set_gemm_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2}[args.gemm])
     note('model on device, %d params; warmup' % sum(p.numel() for p in model.parameters()))
     for i in range(args.warmup):
         ts.step(imgs, tg)
@@ -357,24 +359,25 @@ def main():
             ts.step(imgs, tg)
         torch.cuda.synchronize()
         timer.on = False
-    split = None
+    split = {}
     if args.gemm == 'fp32' and not args.no_split_probe:
-        # Not the headline: the same step with the opt-in split-bf16 GEMM arithmetic, reported beside it.
-        _lib.set_gemm_precision(1)
+        # Not the headline: the same step with the opt-in split-bf16 GEMM arithmetics, reported beside it.
         ts.use_graph = False
-        for _ in range(2):
-            ts.step(imgs, tg)
-        barrier()
-        t1 = time.perf_counter()
-        n_split = min(args.steps, 5)
-        for _ in range(n_split):
-            loss_s, _ = ts.step(imgs, tg)
-        barrier()
-        split = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if ddp:
-            dist.all_reduce(split, op=dist.ReduceOp.MAX)
-        split = float(split) / n_split
-        assert torch.isfinite(loss_s).all()
+        for name, mode in (('bf16x6', 2), ('bf16x3', 1)):
+            _lib.set_gemm_precision(mode)
+            for _ in range(2):
+                ts.step(imgs, tg)
+            barrier()
+            t1 = time.perf_counter()
+            n_split = min(args.steps, 5)
+            for _ in range(n_split):
+                loss_s, _ = ts.step(imgs, tg)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if ddp:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            split[name] = float(tt) / n_split
+            assert torch.isfinite(loss_s).all()
         _lib.set_gemm_precision(0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -389,7 +392,8 @@ def main():
             'metric': 'paired RGB+IR img/s (train step, %dx%d %s two-stream)' % (size, size, 'yolov5x' if args.workload == 'x_1280' else 'yolov5s' if args.workload.startswith('s_') else 'yolov5l'), 'value': round(value, 3),
             'unit': 'paired img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.gemm == 'fp32' else 'f32 storage and accumulation, products as 3 bf16 MFMAs (hi*hi+hi*lo+lo*hi)',
+            'dtype': {'fp32': 'f32', 'bf16x6': 'f32 storage/accumulation, products as 6 bf16 MFMAs of a 3-term split',
+                      'bf16x3': 'f32 storage/accumulation, products as 3 bf16 MFMAs of a 2-term split'}[args.gemm],
             'data': 'synthetic',
             'config': {'workload': {'l_fourier': 'yolov5l two-stream-fourier (default YAML, CEM+FFM+3xGPT), nc=6',
                                     's_fourier': 'yolov5s two-stream-fourier (GPT1_fourier[64]), nc=6',
@@ -419,12 +423,16 @@ def main():
                                'per_call': {k: {'TFLOP/s_while_sharing_the_chip': round(v[0] / (v[1] * 1e-3) / 1e12, 2), 'sum_launch_ms_per_step': round(v[1] / roof_steps, 3),
                                                 'launches_per_step': v[2] // roof_steps} for k, v in per.items()},
                                'step_algorithmic_TFLOP/s': round(3 * WORKLOADS[args.workload][6] * 1e9 * value / 1e12, 2)}
-        if split is not None:
-            out['split_bf16_optional'] = {
-                'value': round(world * bs / split, 3), 'unit': 'paired img/s', 'ms_per_step': round(split * 1e3, 3),
-                'what': 'NOT the headline: same step with mmi_set_gemm_precision(1): every conv/linear GEMM (fwd, dgrad, wgrad) '
-                        'forms an fp32 product as hi*hi + hi*lo + lo*hi of bf16 halves on v_mfma_f32_32x32x16_bf16 with fp32 '
-                        'accumulation (relative error of a GEMM result vs the fp32-MFMA kernels 4.5e-6); off by default'}
+        if split:
+            what = {'bf16x6': 'three bf16 terms per operand, six products of total order <= 2 on v_mfma_f32_32x32x16_bf16, fp32 '
+                              'accumulation: fp32-level accuracy (a GEMM differs from the fp32-MFMA kernel by 3e-7..1e-6, whole-step '
+                              'gradients vs the oracle 5e-5 as with exact fp32)',
+                    'bf16x3': 'two bf16 terms, three products: a GEMM is off by 4.5e-6, predictions 3e-5, whole-step gradients ~1e-3'}
+            out['gemm_modes_optional'] = {
+                'note': 'NOT the headline (which uses exact fp32 MFMA products): the same step with mmi_set_gemm_precision(2 / 1); '
+                        'off by default, see DESIGN.md',
+                **{k: {'value': round(world * bs / v, 3), 'unit': 'paired img/s', 'ms_per_step': round(v * 1e3, 3), 'arithmetic': what[k]}
+                   for k, v in split.items()}}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         sys.stdout.flush()

@@ -210,6 +210,8 @@ struct SkRange {
 // operand is split into two bf16 terms when it is staged into LDS, x = hi + lo with |x - hi - lo| <= 2^-17 |x|, and a product
 // is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 instructions of 8 passes per 16 k instead
 // of 8 instructions of 16 passes, relative error of a product <= 2^-16 (the dropped lo*lo term is 2^-18).
+// PREC = 2: three bf16 terms per operand (x = t0 + t1 + t2, residual <= 2^-25 |x|) and the six products of total order <= 2
+// (t0*t0, t0*t1, t1*t0, t0*t2, t2*t0, t1*t1): fp32-level accuracy (dropped terms <= 2^-24) at 6 x 8 passes per 16 k.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -224,24 +226,34 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int row_bytes) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+// x -> NP bf16 terms, each the rounded residual of the previous ones
+template <int NP>
+__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    float r = v[i];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      t[k][i] = (__bf16)r;
+      r -= (float)t[k][i];
+    }
   }
 }
 
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) void igemm_kernel(IgemmP p) {
-  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 form exists for the vector loaders only");
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? 3 : 2) void igemm_kernel(IgemmP p) {
+  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
+  constexpr int NP = PREC == 0 ? 1 : PREC + 1;      // bf16 planes per operand
+  // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (36 or 52 floats: both make
+  // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
+  constexpr int RSF = PREC == 2 ? 52 : LDS_PAD;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
-  constexpr int A_ELEMS = BM * LDS_PAD;
+  constexpr int A_ELEMS = BM * RSF;
   // split-bf16 dgrad: the weight tile stays k-major ([k][n], as it comes from OHWI memory) in two bf16 planes whose rows are
   // padded by 64 B (conflict-free ds_read_b64_tr_b16: the MFMA B operand is fetched with the hardware transpose read)
   constexpr int B_RSB = BN * 2 + 64;                                  // bytes per k row of one plane
-  constexpr int B_ELEMS = DGRAD ? (PREC == 1 ? 2 * BK * B_RSB / 4 : BK * BN) : BN * LDS_PAD;
+  constexpr int B_ELEMS = DGRAD ? (PREC >= 1 ? NP * BK * B_RSB / 4 : BK * BN) : BN * RSF;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   constexpr int RB = BN / RPP;                      // fwd: B rows per loader thread
   constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
@@ -393,34 +405,34 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
     auto lstore = [&](int stage) {
       float* As = smem + stage * STAGE;
       float* Bs = As + A_ELEMS;
-      if constexpr (PREC == 1) {
-        // row record = 36 floats as in the fp32 form: 32 bf16 "hi" (64 B) | 32 bf16 "lo" (64 B) | 16 B pad
+      if constexpr (PREC >= 1) {
+        // row record: NP planes of 32 bf16 (64 B each) | 16 B pad
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          bf16x4 hi, lo;
-          split_bf16(ra[i], hi, lo);
-          __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPP * i) * LDS_PAD);
-          *reinterpret_cast<bf16x4*>(row + kq) = hi;
-          *reinterpret_cast<bf16x4*>(row + 32 + kq) = lo;
+          bf16x4 tm[NP];
+          split_bf16<NP>(ra[i], tm);
+          __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPP * i) * RSF);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
         }
         if constexpr (!DGRAD) {
 #pragma unroll
           for (int i = 0; i < RB; ++i) {
-            bf16x4 hi, lo;
-            split_bf16(rb[i], hi, lo);
-            __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrow + RPP * i) * LDS_PAD);
-            *reinterpret_cast<bf16x4*>(row + kq) = hi;
-            *reinterpret_cast<bf16x4*>(row + 32 + kq) = lo;
+            bf16x4 tm[NP];
+            split_bf16<NP>(rb[i], tm);
+            __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrow + RPP * i) * RSF);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
           }
         } else {
           char* base = reinterpret_cast<char*>(Bs);
 #pragma unroll
           for (int i = 0; i < KB_IT; ++i) {
-            bf16x4 hi, lo;
-            split_bf16(rb[i], hi, lo);
+            bf16x4 tm[NP];
+            split_bf16<NP>(rb[i], tm);
             char* dst = base + (t / VPR + RPI * i) * B_RSB + (t % VPR) * 8;
-            *reinterpret_cast<bf16x4*>(dst) = hi;
-            *reinterpret_cast<bf16x4*>(dst + BK * B_RSB) = lo;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
           }
         }
         return;
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
       advance();
       const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
       const float* Bs = As + A_ELEMS;
-      if constexpr (PREC == 1) {
+      if constexpr (PREC >= 1) {
 #pragma unroll
         for (int kb = 0; kb < BK / 16; ++kb) {
           // the next slab's global loads: two thirds ahead of the first 16-k block, the rest ahead of the second
@@ -457,19 +469,19 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
 #pragma unroll
           for (int i = 0; i < NB; ++i)
             if (kb == 0 ? ((RA + i) % 3 != 2) : ((RA + i) % 3 == 2)) load_b_row(i);
-          bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+          bf16x8 af[NP][TM], bf[NP][TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const float* row = As + (wm * WM + i * 32 + l31) * LDS_PAD + kb * 8 + lh * 4;   // float index = byte offset / 4
-            ah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row));
-            al[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16));
+            const float* row = As + (wm * WM + i * 32 + l31) * RSF + kb * 8 + lh * 4;   // float index = byte offset / 4
+#pragma unroll
+            for (int k = 0; k < NP; ++k) af[k][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16 * k));
           }
           if constexpr (!DGRAD) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              const float* row = Bs + (wn * WN + j * 32 + l31) * LDS_PAD + kb * 8 + lh * 4;
-              bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row));
-              bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16));
+              const float* row = Bs + (wn * WN + j * 32 + l31) * RSF + kb * 8 + lh * 4;
+#pragma unroll
+              for (int k = 0; k < NP; ++k) bf[k][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(row + 16 * k));
             }
           } else {
             // transposed read: per 16-lane group a block of 4 k-rows x 16 columns; lane 4q+p supplies row q, columns 4p..4p+3
@@ -477,19 +489,20 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32) ? 3 : 2) v
             const int q = (lane & 15) >> 2, pp = lane & 3, m0 = ((lane >> 4) & 1) * 16;
             const char* base = reinterpret_cast<const char*>(Bs) + (kb * 16 + lh * 8 + q) * B_RSB + (wn * WN + m0 + 4 * pp) * 2;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              bh[j] = tr_read8(base + j * 64, B_RSB);
-              bl[j] = tr_read8(base + j * 64 + BK * B_RSB, B_RSB);
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int k = 0; k < NP; ++k) bf[k][j] = tr_read8(base + j * 64 + k * BK * B_RSB, B_RSB);
           }
+          // products of total order <= NP-1, smallest terms first
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int o = NP - 1; o >= 0; --o)
+#pragma unroll
+                for (int ka = 0; ka <= o; ++ka)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ka][i], bf[o - ka][j], acc[i][j], 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -637,15 +650,16 @@ struct WgradP {
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
 
 template <int BM, int BN, bool VEC, int PREC = 0>
-__global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) {
-  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 form exists for the vector loaders only");
+__global__ __launch_bounds__(256, (BK == 32 && PREC < 2) ? 3 : 2) void wgrad_kernel(WgradP p) {
+  static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
+  constexpr int NP = PREC == 0 ? 1 : PREC + 1;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
   // split-bf16 (PREC = 1): both tiles stay k-major in two bf16 planes with rows padded by 64 B; the MFMA operands (8
   // consecutive pixels of one channel) come out of ds_read_b64_tr_b16
   constexpr int A_RSB = BM * 2 + 64, B_RSB = BN * 2 + 64;
-  constexpr int A_ELEMS = PREC == 1 ? 2 * BK * A_RSB / 4 : BK * BM, B_ELEMS = PREC == 1 ? 2 * BK * B_RSB / 4 : BK * BN;
+  constexpr int A_ELEMS = PREC >= 1 ? NP * BK * A_RSB / 4 : BK * BM, B_ELEMS = PREC >= 1 ? NP * BK * B_RSB / 4 : BK * BN;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   __shared__ __align__(16) float smem[MMI_WGRAD_STAGES * STAGE];
 
@@ -767,25 +781,25 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
   auto lstore = [&](int stage) {
     float* As = smem + stage * STAGE;
     float* Bs = As + A_ELEMS;
-    if constexpr (PREC == 1) {
+    if constexpr (PREC >= 1) {
       char* ab = reinterpret_cast<char*>(As);
       char* bb = reinterpret_cast<char*>(Bs);
 #pragma unroll
       for (int i = 0; i < ITA; ++i) {
-        bf16x4 hi, lo;
-        split_bf16(ra[i], hi, lo);
+        bf16x4 tm[NP];
+        split_bf16<NP>(ra[i], tm);
         char* dst = ab + (akr + RPA * i) * A_RSB + (t % VA) * 8;
-        *reinterpret_cast<bf16x4*>(dst) = hi;
-        *reinterpret_cast<bf16x4*>(dst + BK * A_RSB) = lo;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * A_RSB) = tm[k];
         if (want_bias) bsum += ra[i];
       }
 #pragma unroll
       for (int i = 0; i < ITB; ++i) {
-        bf16x4 hi, lo;
-        split_bf16(rb[i], hi, lo);
+        bf16x4 tm[NP];
+        split_bf16<NP>(rb[i], tm);
         char* dst = bb + (bkr + RPB * i) * B_RSB + (t % VB) * 8;
-        *reinterpret_cast<bf16x4*>(dst) = hi;
-        *reinterpret_cast<bf16x4*>(dst + BK * B_RSB) = lo;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
       }
       return;
     }
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
     const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
-    if constexpr (PREC == 1) {
+    if constexpr (PREC >= 1) {
       const int q = (lane & 15) >> 2, pp = lane & 3, m0 = ((lane >> 4) & 1) * 16;
 #pragma unroll
       for (int kb = 0; kb < BK / 16; ++kb) {
@@ -821,25 +835,23 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void wgrad_kernel(WgradP p) 
           if (kb == 0 ? ((ITA + i) % 3 != 2) : ((ITA + i) % 3 == 2)) load_b_row(i);
         const char* ab = reinterpret_cast<const char*>(As) + (kb * 16 + lh * 8 + q) * A_RSB + (wm * WM + m0 + 4 * pp) * 2;
         const char* bb = reinterpret_cast<const char*>(Bs) + (kb * 16 + lh * 8 + q) * B_RSB + (wn * WN + m0 + 4 * pp) * 2;
-        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        bf16x8 af[NP][TM], bf[NP][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          ah[i] = tr_read8(ab + i * 64, A_RSB);
-          al[i] = tr_read8(ab + i * 64 + BK * A_RSB, A_RSB);
-        }
+        for (int k = 0; k < NP; ++k) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh[j] = tr_read8(bb + j * 64, B_RSB);
-          bl[j] = tr_read8(bb + j * 64 + BK * B_RSB, B_RSB);
+          for (int i = 0; i < TM; ++i) af[k][i] = tr_read8(ab + i * 64 + k * BK * A_RSB, A_RSB);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[k][j] = tr_read8(bb + j * 64 + k * BK * B_RSB, B_RSB);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int o = NP - 1; o >= 0; --o)
+#pragma unroll
+              for (int ka = 0; ka <= o; ++ka)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ka][i], bf[o - ka][j], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -976,13 +988,16 @@ int device_cus() {
 // Resident workgroups per CU of a stream-K kernel variant (registers and LDS decide; 3 by the launch bound).
 template <bool DGRAD>
 int sk_occupancy(int bn) {
-  static int cache[2] = {0, 0};
-  int& c = cache[bn == 128 ? 1 : 0];
+  static int cache[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  int& c = cache[g_gemm_prec][bn == 128 ? 1 : 0];
   if (c == 0) {
     int n = 0;
-    hipError_t e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true>, 256, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true>, 256, 0);
-    c = (e == hipSuccess && n > 0) ? n : 3;
+    hipError_t e;
+#define OCC(P_) (bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, P_>, 256, 0) \
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, P_>, 256, 0))
+    e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : OCC(2));
+#undef OCC
+    c = (e == hipSuccess && n > 0) ? n : (g_gemm_prec == 2 ? 2 : 3);
     (void)hipGetLastError();
   }
   return c;
@@ -1054,6 +1069,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
+    if (g_gemm_prec == 2) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
     if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true>), grid, block, 0, s, p);
     MMI_CHECK_LAUNCH(who);
@@ -1062,8 +1083,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false>), grid, block, 0, s, p)
-  if (vec && g_gemm_prec == 1) {
-#define LAUNCH_B3(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1>), grid, block, 0, s, p)
+  if (vec && g_gemm_prec >= 1) {
+#define LAUNCH_B3(BM_, BN_)                                                                                          \
+  do {                                                                                                               \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2>), grid, block, 0, s, p);                  \
+  } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
     else LAUNCH_B3(64, 64);
@@ -1112,7 +1137,7 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d) {
 }  // namespace
 
 extern "C" int mmi_set_gemm_precision(int mode) {
-  MMI_CHECK_ARG(mode == 0 || mode == 1, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = split-bf16 products)", mode);
+  MMI_CHECK_ARG(mode >= 0 && mode <= 2, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = 2-term, 2 = 3-term split-bf16)", mode);
   g_gemm_prec = mode;
   return MMI_OK;
 }
@@ -1227,7 +1252,9 @@ int wgrad_slots(int bm, int bn, bool vec) {
     if (idx == 0 || idx == 4) cache[idx] = 2;  // 64x64: long K chunks stream better than many short ones (measured)
     (void)hipGetLastError();
   }
-  return cache[idx] * device_cus();
+  // (the three-term split variants hold 1.5x the LDS and more registers: two workgroups per CU for the wide tiles)
+  const int per_cu = (g_gemm_prec == 2 && idx >= 1 && idx <= 3 && cache[idx] > 2) ? 2 : cache[idx];
+  return per_cu * device_cus();
 }
 
 WgPlan wgrad_plan(const mmi_conv_desc* d) {
@@ -1315,8 +1342,12 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
-  if (g.vec && g_gemm_prec == 1) {
-#define LAUNCHW3(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p)
+  if (g.vec && g_gemm_prec >= 1) {
+#define LAUNCHW3(BM_, BN_)                                                                              \
+  do {                                                                                                  \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p);  \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p);                   \
+  } while (0)
     if (g.bm == 128 && g.bn == 128) LAUNCHW3(128, 128);
     else if (g.bm == 128) LAUNCHW3(128, 64);
     else if (g.bn == 128) LAUNCHW3(64, 128);

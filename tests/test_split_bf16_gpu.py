@@ -1,5 +1,6 @@
-"""GPU parity of the OPT-IN split-bf16 GEMM arithmetic (mmi_set_gemm_precision(1), csrc/igemm.hip PREC = 1): every fp32
-product formed as hi*hi + hi*lo + lo*hi of bf16 halves on v_mfma_f32_32x32x16_bf16, fp32 accumulation.  Same checks and
+"""GPU parity of the OPT-IN split-bf16 GEMM arithmetics (mmi_set_gemm_precision, csrc/igemm.hip PREC): mode 1 = two bf16
+terms per operand, three products (hi*hi + hi*lo + lo*hi); mode 2 = three terms, the six products of total order <= 2
+(fp32-level accuracy); both on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same checks and
 the same tolerances as the default fp32-MFMA path for every op and for the model's forward and loss; the whole-step
 parameter gradients get the looser bound they need (see test_train_step_split_bf16_matches_oracle)."""
 import pytest
@@ -11,10 +12,11 @@ from test_ops_gpu import CONV_CASES, close, cl, dev, nchw, nhwc, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def split_bf16():
+@pytest.fixture(params=[1, 2], ids=['bf16x3', 'bf16x6'])
+def split_bf16(request):
     from mmidet_hip import lib
-    lib.set_gemm_precision(1)
+    lib.set_gemm_precision(request.param)
+    lib.mode = request.param
     yield lib
     lib.set_gemm_precision(0)
     lib.set_streamk_slots(0)
@@ -91,13 +93,19 @@ def test_train_step_split_bf16_matches_oracle(kind, split_bf16):
     og = dict(o.named_parameters())
     errs = sorted(rel_err(p.grad, og[n].grad) for n, p in m.named_parameters()
                   if og[n].grad is not None and p.grad is not None and float(og[n].grad.norm()) > 1e-5)
-    assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 2e-2, (errs[len(errs) // 2], errs[-1])
+    if split_bf16.mode == 2:      # three-term split: the budget of the fp32 path (test_every_parameter_gradient_vs_oracle)
+        assert errs[-1] < 2e-3, errs[-1]
+    else:
+        assert errs[len(errs) // 2] < 5e-3 and errs[-1] < 2e-2, (errs[len(errs) // 2], errs[-1])
 
 
+@pytest.mark.parametrize('mode,tol', [(1, 2e-5), (2, 5e-6)], ids=['bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('shape', [(16, 80, 80, 128, 128, 3, 1), (16, 160, 160, 128, 256, 3, 2), (16, 40, 40, 512, 256, 1, 1)])
-def test_full_size_layers_split_bf16_vs_fp32_mfma(shape):
+def test_full_size_layers_split_bf16_vs_fp32_mfma(shape, mode, tol):
     """BASELINE-size layers: forward, dgrad and wgrad of the split form against the exact fp32-MFMA kernels.  A product
-    carries <= 2^-16 relative error and the errors of a K-long sum average out: 2e-5 is a loose bound (measured 4.5e-6)."""
+    of the two-term form carries <= 2^-16 relative error and the errors of a K-long sum average out: 2e-5 is a loose bound
+    (measured 4.5e-6); the three-term form differs from the fp32 kernels by what two fp32 summation orders differ by
+    (measured 3e-7..3.6e-6 on wgrad's 100 K-long sums)."""
     from mmidet_hip import lib, ops
     N, H, W, Cin, Cout, k, s = shape
     d = dev()
@@ -108,8 +116,8 @@ def test_full_size_layers_split_bf16_vs_fp32_mfma(shape):
     desc = ops._desc((N, H, W, Cin), Cout, k, s, Cin, Cout)
     dy = torch.randn(N, desc.Ho, desc.Wo, Cout, generator=g).to(d)
     res = {}
-    for mode in (0, 1):
-        lib.set_gemm_precision(mode)
+    for md in (0, mode):
+        lib.set_gemm_precision(md)
         try:
             y = torch.empty(N, desc.Ho, desc.Wo, Cout, device=d)
             dx = torch.empty_like(x)
@@ -120,8 +128,8 @@ def test_full_size_layers_split_bf16_vs_fp32_mfma(shape):
             ops.conv_dgrad(dy, w, dx, desc, st)
             lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
             torch.cuda.synchronize()
-            res[mode] = (y, dx, dw)
+            res[md] = (y, dx, dw)
         finally:
             lib.set_gemm_precision(0)
-    for name, a, b in zip(('y', 'dx', 'dw'), res[1], res[0]):
-        close(a, b, tol=2e-5, what=name + ' split-bf16 vs fp32 MFMA')
+    for name, a, b in zip(('y', 'dx', 'dw'), res[mode], res[0]):
+        close(a, b, tol=tol, what=name + ' split-bf16 vs fp32 MFMA')

@@ -14,7 +14,7 @@ from test_ops_gpu import dev, rel_err  # noqa: E402
 from utils.loss import ComputeLoss  # noqa: E402
 
 for seed in (2, 3, 4):
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         lib.set_gemm_precision(mode)
         m, o, cfg = build_pair('fourier', 128)
         imgs, targets = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=seed)

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from mmidet_hip import lib, ops  # noqa: E402
 from bench_conv import timeit  # noqa: E402
 
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # 1 = two-term split (3 products), 2 = three-term (6 products)
 d = torch.device('cuda:0')
 st = torch.cuda.current_stream().cuda_stream
 SHAPES = [(16, 80, 80, 128, 128, 3, 1), (16, 40, 40, 256, 256, 3, 1), (16, 20, 20, 512, 512, 3, 1), (16, 160, 160, 64, 64, 3, 1),
@@ -21,7 +22,7 @@ for (B, H, W, Ci, Co, k, s) in SHAPES:
     desc = ops._desc((B, H, W, Ci), Co, k, s, Ci, Co)
     fl = 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k
     res = {}
-    for mode in (0, 1):
+    for mode in (0, MODE):
         lib.set_gemm_precision(mode)
         try:
             y = torch.empty(B, desc.Ho, desc.Wo, Co, device=d)
@@ -37,10 +38,10 @@ for (B, H, W, Ci, Co, k, s) in SHAPES:
             res[mode] = (y.clone(), t, dx.clone(), t2, dw.clone(), t3)
         finally:
             lib.set_gemm_precision(0)
-    e = float((res[1][0].double() - res[0][0].double()).norm() / res[0][0].double().norm())
-    e2 = float((res[1][2].double() - res[0][2].double()).norm() / res[0][2].double().norm())
-    e3 = float((res[1][4].double() - res[0][4].double()).norm() / res[0][4].double().norm())
+    e = float((res[MODE][0].double() - res[0][0].double()).norm() / res[0][0].double().norm())
+    e2 = float((res[MODE][2].double() - res[0][2].double()).norm() / res[0][2].double().norm())
+    e3 = float((res[MODE][4].double() - res[0][4].double()).norm() / res[0][4].double().norm())
     print('%-30s %8.1f %8.1f %5.2f %8.1e | %8.1f %8.1f %5.2f %8.1e | %8.1f %8.1f %5.2f %8.1e' % (
-        str((B, H, W, Ci, Co, k, s)), fl / res[0][1] / 1e9, fl / res[1][1] / 1e9, res[0][1] / res[1][1], e,
-        fl / res[0][3] / 1e9, fl / res[1][3] / 1e9, res[0][3] / res[1][3], e2,
-        fl / res[0][5] / 1e9, fl / res[1][5] / 1e9, res[0][5] / res[1][5], e3), flush=True)
+        str((B, H, W, Ci, Co, k, s)), fl / res[0][1] / 1e9, fl / res[MODE][1] / 1e9, res[0][1] / res[MODE][1], e,
+        fl / res[0][3] / 1e9, fl / res[MODE][3] / 1e9, res[0][3] / res[MODE][3], e2,
+        fl / res[0][5] / 1e9, fl / res[MODE][5] / 1e9, res[0][5] / res[MODE][5], e3), flush=True)
