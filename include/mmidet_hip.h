@@ -58,9 +58,11 @@ int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
  * shape with >= 2 K slabs (lets small test shapes take the schedule), n < 0 = schedule off.  Returns the old value.
  * Changes what the *_workspace() and row_blocks() queries answer: set it before planning a call, not between. */
 int mmi_set_streamk_slots(int slots);
-/* Arithmetic of the forward-layout GEMMs (conv / linear forward): 0 (default) = exact fp32 products on
- * v_mfma_f32_32x32x2_f32; 1 (opt-in) = each fp32 operand split into two bf16 terms, product = hi*hi + hi*lo + lo*hi on
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative product error <= 2^-16).  dgrad / wgrad stay fp32. */
+/* Arithmetic of the conv / linear GEMMs (forward, dgrad, wgrad).  0 (default): exact fp32 products on
+ * v_mfma_f32_32x32x2_f32.  Opt-in split forms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, each fp32 operand split
+ * into bf16 terms when its tile is staged into LDS: 1 = two terms, three products (relative product error <= 2^-16);
+ * 2 = three terms, the six products of total order <= 2 (dropped terms <= 2^-24: fp32-level results); 3 = three terms, all
+ * nine products (each fp32 product exact).  A process-wide switch; takes effect at the next launch. */
 int mmi_set_gemm_precision(int mode);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */

@@ -212,6 +212,8 @@ struct SkRange {
 // of 8 instructions of 16 passes, relative error of a product <= 2^-16 (the dropped lo*lo term is 2^-18).
 // PREC = 2: three bf16 terms per operand (x = t0 + t1 + t2, residual <= 2^-25 |x|) and the six products of total order <= 2
 // (t0*t0, t0*t1, t1*t0, t0*t2, t2*t0, t1*t1): fp32-level accuracy (dropped terms <= 2^-24) at 6 x 8 passes per 16 k.
+// PREC = 3: the same three terms -- which represent a 24-bit significand exactly -- and all nine products, each exact in
+// fp32: every fp32 product is formed exactly, as by the fp32 MFMA; only the order of the fp32 accumulation differs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -243,10 +245,11 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? 3 : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
-  constexpr int NP = PREC == 0 ? 1 : PREC + 1;      // bf16 planes per operand
+  constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
+  constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;                // highest total order of the products kept
   // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (36 or 52 floats: both make
   // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
-  constexpr int RSF = PREC == 2 ? 52 : LDS_PAD;
+  constexpr int RSF = PREC >= 2 ? 52 : LDS_PAD;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * RSF;
@@ -499,9 +502,9 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-              for (int o = NP - 1; o >= 0; --o)
+              for (int o = OL; o >= 0; --o)
 #pragma unroll
-                for (int ka = 0; ka <= o; ++ka)
+                for (int ka = (o > NP - 1 ? o - (NP - 1) : 0); ka <= (o < NP - 1 ? o : NP - 1); ++ka)
                   acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ka][i], bf[o - ka][j], acc[i][j], 0, 0, 0);
         }
       } else {
@@ -652,7 +655,8 @@ struct WgradP {
 template <int BM, int BN, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(256, (BK == 32 && PREC < 2) ? 3 : 2) void wgrad_kernel(WgradP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
-  constexpr int NP = PREC == 0 ? 1 : PREC + 1;
+  constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);
+  constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
@@ -848,9 +852,9 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC < 2) ? 3 : 2) void wgrad_ker
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int o = NP - 1; o >= 0; --o)
+            for (int o = OL; o >= 0; --o)
 #pragma unroll
-              for (int ka = 0; ka <= o; ++ka)
+              for (int ka = (o > NP - 1 ? o - (NP - 1) : 0); ka <= (o < NP - 1 ? o : NP - 1); ++ka)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ka][i], bf[o - ka][j], acc[i][j], 0, 0, 0);
       }
     } else {
@@ -988,16 +992,16 @@ int device_cus() {
 // Resident workgroups per CU of a stream-K kernel variant (registers and LDS decide; 3 by the launch bound).
 template <bool DGRAD>
 int sk_occupancy(int bn) {
-  static int cache[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  static int cache[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
   int& c = cache[g_gemm_prec][bn == 128 ? 1 : 0];
   if (c == 0) {
     int n = 0;
     hipError_t e;
 #define OCC(P_) (bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, P_>, 256, 0) \
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, P_>, 256, 0))
-    e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : OCC(2));
+    e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : (g_gemm_prec == 2 ? OCC(2) : OCC(3)));
 #undef OCC
-    c = (e == hipSuccess && n > 0) ? n : (g_gemm_prec == 2 ? 2 : 3);
+    c = (e == hipSuccess && n > 0) ? n : (g_gemm_prec >= 2 ? 2 : 3);
     (void)hipGetLastError();
   }
   return c;
@@ -1075,6 +1079,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
+    if (g_gemm_prec == 3) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
     if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true>), grid, block, 0, s, p);
     MMI_CHECK_LAUNCH(who);
@@ -1087,7 +1097,8 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
 #define LAUNCH_B3(BM_, BN_)                                                                                          \
   do {                                                                                                               \
     if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2>), grid, block, 0, s, p);                  \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3>), grid, block, 0, s, p);                  \
   } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
@@ -1137,7 +1148,7 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d) {
 }  // namespace
 
 extern "C" int mmi_set_gemm_precision(int mode) {
-  MMI_CHECK_ARG(mode >= 0 && mode <= 2, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = 2-term, 2 = 3-term split-bf16)", mode);
+  MMI_CHECK_ARG(mode >= 0 && mode <= 3, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9)", mode);
   g_gemm_prec = mode;
   return MMI_OK;
 }
@@ -1253,7 +1264,7 @@ int wgrad_slots(int bm, int bn, bool vec) {
     (void)hipGetLastError();
   }
   // (the three-term split variants hold 1.5x the LDS and more registers: two workgroups per CU for the wide tiles)
-  const int per_cu = (g_gemm_prec == 2 && idx >= 1 && idx <= 3 && cache[idx] > 2) ? 2 : cache[idx];
+  const int per_cu = (g_gemm_prec >= 2 && idx >= 1 && idx <= 3 && cache[idx] > 2) ? 2 : cache[idx];
   return per_cu * device_cus();
 }
 
@@ -1346,7 +1357,8 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
 #define LAUNCHW3(BM_, BN_)                                                                              \
   do {                                                                                                  \
     if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p);  \
-    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p);                   \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3>), grid, block, 0, s, p);                   \
   } while (0)
     if (g.bm == 128 && g.bn == 128) LAUNCHW3(128, 128);
     else if (g.bm == 128) LAUNCHW3(128, 64);
