@@ -202,6 +202,62 @@ __global__ void spp_bwd_kernel(const float* __restrict__ x, int ldx, const float
   }
 }
 
+// SPP backward, tiled form: one workgroup = one image x CG channels with the whole H x W map in LDS.  The arg-max of a
+// (2r+1)^2 window with ATen's tie rule (first maximum in row-major order) is separable: per row the first column holding the
+// row-window maximum, then the first row holding the maximum of those -- 2(2r+1) compares instead of (2r+1)^2, all from
+// LDS; the three pools' gradients and the identity branch are summed in an LDS accumulator (LDS float atomics: a handful of
+// colliding adders) and written once, coalesced.
+template <int CG>
+__global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat,
+                                                            int ldd, float* __restrict__ dx, int lddx, int H, int W, int C) {
+  extern __shared__ __align__(16) unsigned char spp_smem[];
+  const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * CG, E = HW * CG;
+  float* xs = reinterpret_cast<float*>(spp_smem);   // [HW][CG]
+  float* rv = xs + E;                                // row-window maxima
+  float* acc = rv + E;                               // gradient accumulator
+  unsigned char* rc = reinterpret_cast<unsigned char*>(acc + E);   // column of the row-window maximum (W <= 255)
+  const int t = threadIdx.x;
+  for (int e = t; e < E; e += 256) {
+    const int pix = e / CG, c = e - pix * CG;
+    const bool ok = c0 + c < C;
+    xs[e] = ok ? x[((int64_t)n * HW + pix) * ldx + c0 + c] : 0.f;
+    acc[e] = ok ? dcat[((int64_t)n * HW + pix) * ldd + c0 + c] : 0.f;   // identity branch of the concat
+  }
+  __syncthreads();
+  for (int pk = 0; pk < 3; ++pk) {
+    const int rad = 2 + 2 * pk;
+    for (int e = t; e < E; e += 256) {
+      const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
+      float best = -INFINITY;
+      int bw = -1;
+      for (int ww = max(w - rad, 0); ww <= min(w + rad, W - 1); ++ww) {
+        const float v = xs[(h * W + ww) * CG + c];
+        if (v > best || bw < 0) best = v, bw = ww;
+      }
+      rv[e] = best;
+      rc[e] = (unsigned char)bw;
+    }
+    __syncthreads();
+    for (int e = t; e < E; e += 256) {
+      const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
+      if (c0 + c >= C) continue;
+      float best = -INFINITY;
+      int bh = -1;
+      for (int hh = max(h - rad, 0); hh <= min(h + rad, H - 1); ++hh) {
+        const float v = rv[(hh * W + w) * CG + c];
+        if (v > best || bh < 0) best = v, bh = hh;
+      }
+      const int bw = rc[(bh * W + w) * CG + c];
+      atomicAdd(acc + (bh * W + bw) * CG + c, dcat[((int64_t)n * HW + pix) * ldd + (1 + pk) * C + c0 + c]);
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < E; e += 256) {
+    const int pix = e / CG, c = e - pix * CG;
+    if (c0 + c < C) dx[((int64_t)n * HW + pix) * lddx + c0 + c] = acc[e];
+  }
+}
+
 // Detect head: in (B, P=ny*nx, na*no) -> out (B, na, P, no)   [inverse: the gradient goes the other way]
 __global__ void head_permute_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int na, int no,
                                     int P, int inverse) {
@@ -354,6 +410,28 @@ extern "C" int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int 
   MMI_CHECK_ARG(x && dcat && dx && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && ldd >= 4 * C && lddx >= C,
                 "mmi_spp_pool_bwd: bad arguments");
   const int64_t rows = (int64_t)N * H * W;
+  {  // tiled form when the map fits in LDS with at least 4 channels per workgroup (13 bytes per map element)
+    const size_t per_c = (size_t)H * W * 13;
+    const int cg = per_c * 16 <= 150 * 1024 ? 16 : (per_c * 8 <= 150 * 1024 ? 8 : (per_c * 4 <= 150 * 1024 ? 4 : 0));
+    if (cg > 0 && W <= 255) {
+      const dim3 grid(cdiv(C, cg), N), block(256);
+      const size_t lds = per_c * cg;
+      hipStream_t s = (hipStream_t)stream;
+      static bool raised = false;   // dynamic LDS beyond 64 KB has to be allowed per kernel
+      if (!raised) {
+        (void)hipFuncSetAttribute((const void*)spp_bwd_tiled_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)spp_bwd_tiled_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)spp_bwd_tiled_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipGetLastError();
+        raised = true;
+      }
+      if (cg == 16) hipLaunchKernelGGL(spp_bwd_tiled_kernel<16>, grid, block, lds, s, x, ldx, dcat, ldd, dx, lddx, H, W, C);
+      else if (cg == 8) hipLaunchKernelGGL(spp_bwd_tiled_kernel<8>, grid, block, lds, s, x, ldx, dcat, ldd, dx, lddx, H, W, C);
+      else hipLaunchKernelGGL(spp_bwd_tiled_kernel<4>, grid, block, lds, s, x, ldx, dcat, ldd, dx, lddx, H, W, C);
+      MMI_CHECK_LAUNCH("mmi_spp_pool_bwd(tiled)");
+      return MMI_OK;
+    }
+  }
   if (int e = mmi_copy2d(dcat, ldd, dx, lddx, rows, C, stream)) return e;
   hipLaunchKernelGGL(spp_bwd_kernel, dim3(ew_blocks(rows * C * 3)), dim3(256), 0, (hipStream_t)stream, x, ldx, dcat, ldd,
                      dx, lddx, N, H, W, C);
