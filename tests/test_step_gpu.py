@@ -223,3 +223,21 @@ def test_data_parallel_eager_writes_gradients_into_the_buckets():
     finally:
         ops.GRAD_SLOTS.clear()
         dist.destroy_process_group()
+
+
+def test_training_overfits_one_batch():
+    """End-to-end sanity of the step (forward, loss, backward, fused SGD+EMA, BN running stats, warm-up schedule): 40 steps on
+    one batch must bring the detection loss down steadily (measured 0.194 -> 0.141) and leave every parameter and buffer
+    finite."""
+    m, ts, cfg = make(fused_optimizer=True)
+    for g in ts.optimizer.param_groups:
+        g['lr'] = 0.01
+    imgs, tg = batch(cfg, 50)
+    losses = []
+    for it in range(40):
+        loss, items = ts.step(imgs, tg)
+        if it % 13 == 0 or it == 39:
+            losses.append(float(items[3]))           # Detectloss (lbox + lobj + lcls)
+    assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point)
+    assert all(torch.isfinite(v).all() for v in ts.ema.ema.state_dict().values() if v.dtype.is_floating_point)
+    assert losses[-1] < 0.8 * losses[0] and all(b < a for a, b in zip(losses, losses[1:])), losses
