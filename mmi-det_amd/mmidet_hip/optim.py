@@ -17,6 +17,38 @@ _REC = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('ema', '<u8'), ('n
 _CHUNK = 65536  # MMI_OPT_CHUNK
 
 
+class _Staging:
+    """Host -> device upload of a small table through a ring of pinned buffers.  An asynchronous copy reads its pinned source
+    when the stream gets to it, which in an eager run is several steps after the host issued it (the host enqueues a step in
+    half the time the GPU needs); writing the next step's table into the same pinned buffer in the meantime hands the GPU the
+    wrong step's gradient pointers.  Each ring slot is reused only after the copy that last read it has completed."""
+
+    def __init__(self, nbytes, device, depth=4):
+        self.cuda = device.type == 'cuda'
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() if self.cuda else torch.empty(nbytes, dtype=torch.uint8)
+                     for _ in range(depth)]
+        self.done = [None] * depth
+        self.i = 0
+        # a captured copy re-reads its pinned source at every replay: it gets a buffer of its own (allocated here, because
+        # pinning memory is not allowed while a stream is capturing) that the ring never overwrites
+        self.capture_buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if self.cuda else None
+
+    def upload(self, src_u8, dst_dev):
+        if self.cuda and torch.cuda.is_current_stream_capturing():
+            self.capture_buf.copy_(src_u8)
+            dst_dev.copy_(self.capture_buf, non_blocking=True)
+            return
+        k = self.i
+        self.i = (k + 1) % len(self.bufs)
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        self.bufs[k].copy_(src_u8)
+        dst_dev.copy_(self.bufs[k], non_blocking=True)
+        if self.cuda:
+            self.done[k] = torch.cuda.Event()
+            self.done[k].record()
+
+
 class FusedSGDEMA:
     def __init__(self, model, groups, ema_model=None, ema_decay=0.9999, ema_updates=0):
         """groups: list of dicts {'params': [...], 'lr':, 'momentum':, 'weight_decay':} (at most 3)."""
@@ -33,8 +65,9 @@ class FusedSGDEMA:
         self._steps = 0
         self._gptrs = None
         self._recs_host = self._recs_dev = self._chunks_dev = None
-        self._hyper_host = torch.zeros(9, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(9)
+        self._hyper_host = torch.zeros(9, dtype=torch.float32)
         self._hyper_dev = torch.zeros(9, dtype=torch.float32, device=self.device)
+        self._hyper_stage = _Staging(36, self.device)
         self._build()
 
     # ---- table construction ------------------------------------------------------------------------------------------
@@ -72,9 +105,9 @@ class FusedSGDEMA:
         ck = np.array(chunks, dtype=np.int32).reshape(-1, 2)
         self._nchunks = len(chunks)
         self._chunks_dev = torch.from_numpy(ck).to(self.device)
-        self._recs_pinned = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).pin_memory() \
-            if torch.cuda.is_available() else torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
-        self._recs_dev = torch.empty(self._recs_pinned.numel(), dtype=torch.uint8, device=self.device)
+        nbytes = rec.view(np.uint8).reshape(-1).size
+        self._recs_stage = _Staging(nbytes, self.device)
+        self._recs_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _refresh_grads(self):
         """Gradients are fresh tensors every eager step (AccumulateGrad steals them); re-point the table when they move.
@@ -93,8 +126,7 @@ class FusedSGDEMA:
         rec['g'][:n] = np.array(ptrs, dtype=np.uint64)
         al = ((rec['p'] | rec['g'] | rec['buf'] | rec['ema']) & np.uint64(15)) == 0
         rec['flags'] = (rec['flags'] & ~np.int32(4)) | np.where(al, 4, 0).astype(np.int32)
-        self._recs_pinned.copy_(torch.from_numpy(rec.view(np.uint8).reshape(-1)))
-        self._recs_dev.copy_(self._recs_pinned, non_blocking=True)
+        self._recs_stage.upload(torch.from_numpy(rec.view(np.uint8).reshape(-1)), self._recs_dev)
 
     # ---- per step ----------------------------------------------------------------------------------------------------
     def upload_hyper(self, advance=True):
@@ -107,7 +139,7 @@ class FusedSGDEMA:
             g = self.param_groups[min(i, len(self.param_groups) - 1)]
             h[i], h[3 + i] = g['lr'], g['weight_decay']
         h[6], h[7], h[8] = self.param_groups[0]['momentum'], d, 1.0 if self._steps == 0 else 0.0
-        self._hyper_dev.copy_(h, non_blocking=True)
+        self._hyper_stage.upload(h.view(torch.uint8), self._hyper_dev.view(torch.uint8))
         self._steps += 1
 
     def launch(self):
