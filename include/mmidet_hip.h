@@ -61,7 +61,7 @@ int mmi_set_streamk_slots(int slots);
 /* Arithmetic of the conv / linear GEMMs (forward, dgrad, wgrad).  0 (default): exact fp32 products on
  * v_mfma_f32_32x32x2_f32.  Opt-in split forms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, each fp32 operand split
  * into bf16 terms when its tile is staged into LDS: 1 = two terms, three products (relative product error <= 2^-16);
- * 2 = three terms, the six products of total order <= 2 (dropped terms <= 2^-24: fp32-level results); 3 = three terms, all
+ * 2 = three terms, the six products of total order <= 2 (dropped terms <= 2^-24 per product; one GEMM is at fp32 level, full-depth gradients are 4x worse than fp32's); 3 = three terms, all
  * nine products (each fp32 product exact).  A process-wide switch; takes effect at the next launch. */
 int mmi_set_gemm_precision(int mode);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
