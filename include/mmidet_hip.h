@@ -54,6 +54,33 @@ typedef struct {
  * buffer must be ZERO-FILLED when first handed over; every launch leaves it ready for the next one, of any shape, as
  * long as launches sharing a buffer are ordered on one stream. */
 int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
+/* Epilogue forms of the token-side Linear layers, so that a transformer block (models/common.py:1237-1267,
+ * SelfAttention 1147-1235) is 9 dependent kernels forward and 11 backward instead of 14 and 20:
+ *   MMI_EPI_DROPOUT_RESIDUAL  y = aux + dropout(x w^T + bias)      out_proj / mlp[2] + nn.Dropout + the residual add
+ *                             (common.py:1173-1174,1233,1258,1263-1266); mask index = row * Cout + col, as mmi_dropout
+ *                             over the contiguous (rows, Cout) tensor
+ *   MMI_EPI_GELU              aux_out = x w^T + bias; y = GELU(aux_out)          mlp[0] + nn.GELU (common.py:1254-1256)
+ *   MMI_EPI_GELU_GRAD         (dgrad) dx = (dy w) * GELU'(aux)                   backward of the same pair
+ *   MMI_EPI_ACCUMULATE        (dgrad) dx = aux + dy w; aux may alias dx          sum of the q/k/v input gradients */
+#define MMI_EPI_NONE 0
+#define MMI_EPI_DROPOUT_RESIDUAL 1
+#define MMI_EPI_GELU 2
+#define MMI_EPI_GELU_GRAD 3
+#define MMI_EPI_ACCUMULATE 4
+typedef struct {
+  int32_t kind;
+  int32_t ldaux, ldaux_out;
+  float p_drop;
+  const float* aux;
+  float* aux_out;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+} mmi_linear_epilogue;
+/* 1x1 descriptors only (a Linear); workspace as for mmi_conv_fwd / mmi_conv_dgrad with the same descriptor. */
+int mmi_linear_fwd_fused(const float* x, const float* w, const float* bias, float* y, void* workspace,
+                         size_t workspace_bytes, const mmi_conv_desc* d, const mmi_linear_epilogue* e, void* stream);
+int mmi_linear_dgrad_fused(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                           const mmi_conv_desc* d, const mmi_linear_epilogue* e, void* stream);
 /* Tuning/testing knob of the stream-K planner: 0 = size the grid to the chip (default), n > 0 = n workgroups for every
  * shape with >= 2 K slabs (lets small test shapes take the schedule), n < 0 = schedule off.  Returns the old value.
  * Changes what the *_workspace() and row_blocks() queries answer: set it before planning a call, not between. */
@@ -177,6 +204,16 @@ int mmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 int mmi_layernorm_bwd_parts(int rows);
 int mmi_layernorm_bwd(const float* x, const float* gamma, const float* stats, const float* dy, float* dx, float* partials,
                       float* dgamma, float* dbeta, int rows, int C, void* stream); /* partials: parts*2*C floats */
+/* The two halves of mmi_layernorm_bwd for a transformer block's backward (common.py:1263-1266: x = x + sa(ln(x)),
+ * x = x + mlp(ln(x))).  _input sits on the dependency chain: dx = LayerNorm'(dy) [+ dresidual, the gradient arriving over
+ * the skip connection], and optionally dx_dropped = dx * dropout-mask/(1-p) of the branch that produced this block input
+ * (what the Dropout at common.py:1174 / 1258 hands to its Linear in the backward).  _params (dgamma, dbeta) is off the
+ * chain and may run on another stream. */
+int mmi_layernorm_bwd_input(const float* x, const float* gamma, const float* stats, const float* dy, const float* dresidual,
+                            float* dx, float* dx_dropped, float p_drop, uint64_t seed, const uint64_t* seed_dev, int rows,
+                            int C, void* stream);
+int mmi_layernorm_bwd_params(const float* x, const float* stats, const float* dy, float* partials, float* dgamma,
+                             float* dbeta, int rows, int C, void* stream);
 /* SelfAttention core over T=128 tokens (common.py:1206-1231): q,k,v,out are (B,128,heads*dk) with row stride ld; head h
  * owns channels [h*dk,(h+1)*dk).  probs (B,heads,128,128) receives the softmax (saved for backward); attention dropout
  * is regenerated from (seed) in the backward. */

@@ -13,11 +13,24 @@ namespace {
 __device__ __forceinline__ void fold_parts(const float* __restrict__ partials, int p0, int p1, int C, int c, int cl, int pl,
                                            double (*red)[16][16], double& s1, double& s2) {
   s1 = s2 = 0.0;
-  if (c < C)
-    for (int p = p0 + pl; p < p1; p += 16) {
-      s1 += (double)partials[((int64_t)p * 2 + 0) * C + c];
-      s2 += (double)partials[((int64_t)p * 2 + 1) * C + c];
+  if (c < C) {
+    constexpr int U = 16;  // loads of one round are independent: a 1024-part list costs 4 memory latencies, not 64
+    for (int p = p0 + pl; p < p1; p += 16 * U) {
+      float a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pp = p + 16 * u;
+        const bool ok = pp < p1;
+        a[u] = ok ? partials[((int64_t)pp * 2 + 0) * C + c] : 0.0f;
+        b[u] = ok ? partials[((int64_t)pp * 2 + 1) * C + c] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s1 += (double)a[u];
+        s2 += (double)b[u];
+      }
     }
+  }
   red[0][pl][cl] = s1;
   red[1][pl][cl] = s2;
   __syncthreads();

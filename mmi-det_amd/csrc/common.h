@@ -54,6 +54,30 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// ---- counter-based dropout: keep iff hash(seed, index) >= p * 2^32 (tokens.hip kernels and the Linear epilogues) ----
+__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return mix32(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+static inline uint32_t drop_thresh(float p) {
+  if (p <= 0.f) return 0u;
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+// GELU (erf form, nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == MMI_ACT_SILU) return z / (1.0f + expf(-z));

@@ -66,6 +66,14 @@ struct IgemmP {
   int ldr, act;
   float* sk_slots;  // stream-K: 2 partial-tile slots of BM*BN floats per workgroup
   int* sk_count;    // stream-K: per-tile arrival counters (zero before and after every launch)
+  // token-side Linear epilogues (mmi_linear_epilogue): MMI_EPI_*
+  int epi, ldaux, ldaux_out;
+  const float* aux;
+  float* aux_out;
+  uint64_t seed;
+  const uint64_t* seed_dev;
+  uint32_t drop_thresh;
+  float inv_keep;
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -242,7 +250,9 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
   }
 }
 
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0>
+// EPI: the token-side Linear epilogues (p.epi) are compiled in; a separate instantiation, because their registers
+// (64-bit hash, erf) would otherwise cost the convolution kernels occupancy.
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? 3 : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
     }
 
     // ---- epilogue: C/D layout of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const uint64_t epi_seed = EPI ? p.seed + (p.seed_dev != nullptr ? p.seed_dev[0] : 0ull) : 0ull;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WN + j * 32 + l31;
@@ -610,6 +621,20 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
           s2 += v * v;
           if (!DGRAD && p.act != MMI_ACT_NONE) v = act_fwd(v, p.act);  // uniform; training never sets it (BN follows)
           if (!DGRAD && p.res != nullptr && cok && row < Mc) v += p.res[(int64_t)row * p.ldr + col];
+          if (EPI && p.epi != MMI_EPI_NONE && cok && row < Mc) {  // uniform switch; 1x1 only, so `row` is the output row
+            const int64_t ao = (int64_t)row * p.ldaux + col;
+            if (p.epi == MMI_EPI_DROPOUT_RESIDUAL) {
+              if (p.drop_thresh) v *= drop_scale(epi_seed, (uint64_t)((int64_t)row * p.Ncol + col), p.drop_thresh, p.inv_keep);
+              v += p.aux[ao];
+            } else if (p.epi == MMI_EPI_GELU) {
+              p.aux_out[(int64_t)row * p.ldaux_out + col] = v;
+              v = gelu_f(v);
+            } else if (p.epi == MMI_EPI_GELU_GRAD) {
+              v *= gelu_grad_f(p.aux[ao]);
+            } else if (p.epi == MMI_EPI_ACCUMULATE) {
+              v += p.aux[ao];
+            }
+          }
           if (cok && row < Mc) p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
         }
       }
@@ -1047,7 +1072,7 @@ size_t sk_workspace_bytes(const FwdPlan& f) {
   return f.sk_grid > 0 ? SK_COUNTER_BYTES + (size_t)f.sk_grid * 2 * f.bm * f.bn * sizeof(float) : 0;
 }
 
-template <bool DGRAD>
+template <bool DGRAD, bool EPI = false>
 int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s) {
   const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
   IgemmP p = p0;
@@ -1068,37 +1093,37 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     p.sk_slots = (float*)((char*)workspace + SK_COUNTER_BYTES);
     const dim3 grid(f.sk_grid), block(256);
     if (g_gemm_prec == 1) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
     if (g_gemm_prec == 2) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
     if (g_gemm_prec == 3) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
-    if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true>), grid, block, 0, s, p);
+    if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
     MMI_CHECK_LAUNCH(who);
     return MMI_OK;
   }
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
-  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false>), grid, block, 0, s, p)
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p)
   if (vec && g_gemm_prec >= 1) {
 #define LAUNCH_B3(BM_, BN_)                                                                                          \
   do {                                                                                                               \
-    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1>), grid, block, 0, s, p); \
-    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3>), grid, block, 0, s, p);                  \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1, EPI>), grid, block, 0, s, p); \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI>), grid, block, 0, s, p);                  \
   } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
@@ -1108,6 +1133,10 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     return MMI_OK;
   }
   if (!vec) {
+    if (EPI) {
+      mmi_set_error("%s: the fused Linear epilogues need channel counts and row strides that are multiples of 4", who);
+      return MMI_ERR_ARG;
+    }
     if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
     else LAUNCH(64, 64, false);
   } else if (f.bm == 128 && f.bn == 128) LAUNCH(128, 128, true);
@@ -1206,6 +1235,62 @@ int conv_fwd_impl(const float* x, const float* w, const float* bias, const float
   return launch_igemm<false>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 }  // namespace
+
+namespace {
+int fill_epilogue(IgemmP& p, const mmi_conv_desc* d, const mmi_linear_epilogue* e, bool dgrad, const float* out, const char* who) {
+  MMI_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "%s: 1x1 descriptors only", who);
+  if (e == nullptr || e->kind == MMI_EPI_NONE) return MMI_OK;
+  const int cols = dgrad ? d->Cin : d->Cout;
+  const bool fwd_kind = e->kind == MMI_EPI_DROPOUT_RESIDUAL || e->kind == MMI_EPI_GELU;
+  const bool bwd_kind = e->kind == MMI_EPI_GELU_GRAD || e->kind == MMI_EPI_ACCUMULATE;
+  MMI_CHECK_ARG(dgrad ? bwd_kind : fwd_kind, "%s: epilogue kind %d does not belong to this direction", who, e->kind);
+  if (e->kind == MMI_EPI_GELU) {
+    MMI_CHECK_ARG(e->aux_out != nullptr && e->ldaux_out >= cols, "%s: GELU epilogue needs aux_out with ldaux_out >= %d", who, cols);
+  } else {
+    MMI_CHECK_ARG(e->aux != nullptr && e->ldaux >= cols, "%s: epilogue needs aux with ldaux >= %d", who, cols);
+    // only the accumulate form may read what it writes (element by element, same thread)
+    MMI_CHECK_ARG(e->kind == MMI_EPI_ACCUMULATE || e->aux != out, "%s: aux aliases the output", who);
+  }
+  if (e->kind == MMI_EPI_DROPOUT_RESIDUAL)
+    MMI_CHECK_ARG(e->p_drop >= 0.f && e->p_drop < 1.f, "%s: dropout probability %g", who, (double)e->p_drop);
+  p.epi = e->kind; p.aux = e->aux; p.ldaux = e->ldaux; p.aux_out = e->aux_out; p.ldaux_out = e->ldaux_out;
+  p.seed = e->seed; p.seed_dev = e->seed_dev;
+  p.drop_thresh = e->kind == MMI_EPI_DROPOUT_RESIDUAL ? drop_thresh(e->p_drop) : 0u;
+  p.inv_keep = e->kind == MMI_EPI_DROPOUT_RESIDUAL ? 1.0f / (1.0f - e->p_drop) : 1.0f;
+  return MMI_OK;
+}
+}  // namespace
+
+extern "C" int mmi_linear_fwd_fused(const float* x, const float* w, const float* bias, float* y, void* workspace,
+                                    size_t workspace_bytes, const mmi_conv_desc* d, const mmi_linear_epilogue* e,
+                                    void* stream) {
+  if (int err = check_desc(d, "mmi_linear_fwd_fused")) return err;
+  MMI_CHECK_ARG(x && w && y, "mmi_linear_fwd_fused: null pointer");
+  const bool vec = fwd_vec(d);
+  MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mmi_linear_fwd_fused: operands must be 16-byte aligned");
+  IgemmP p{};
+  if (int err = fill_epilogue(p, d, e, false, y, "mmi_linear_fwd_fused")) return err;
+  p.A = x; p.B = w; p.C = y; p.bias = bias;
+  p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = 1; p.KW = 1;
+  p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
+  p.stride = 1; p.pad = 0; p.Ktot = d->Cin; p.ldb = p.Ktot;
+  return launch_igemm<false, true>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mmi_linear_dgrad_fused(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                                      const mmi_conv_desc* d, const mmi_linear_epilogue* e, void* stream) {
+  if (int err = check_desc(d, "mmi_linear_dgrad_fused")) return err;
+  MMI_CHECK_ARG(dy && w && dx, "mmi_linear_dgrad_fused: null pointer");
+  const bool vec = dgrad_vec(d);
+  MMI_CHECK_ARG(!vec || (((uintptr_t)dy | (uintptr_t)w) & 15) == 0, "mmi_linear_dgrad_fused: operands must be 16-byte aligned");
+  IgemmP p{};
+  if (int err = fill_epilogue(p, d, e, true, dx, "mmi_linear_dgrad_fused")) return err;
+  p.A = dy; p.B = w; p.C = dx;
+  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = 1; p.KW = 1;
+  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
+  p.stride = 1; p.pad = 0; p.Ktot = d->Cout; p.ldb = d->Cin;
+  return launch_igemm<true, true>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
 
 extern "C" int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials,
                             void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {

@@ -18,18 +18,7 @@ inline int ew_blocks(int64_t total) {
 #define GRID_STRIDE(e, total) \
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (total); e += (int64_t)gridDim.x * blockDim.x)
 
-// ---- counter-based dropout: keep iff hash(seed, index) >= p * 2^32 -------------------------------------------------
-__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
-}
-__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
-  return mix32(seed, idx) >= thresh ? inv_keep : 0.f;
-}
-
+// ---- counter-based dropout (mix32 / drop_scale: common.h) ----
 // out = (a [+ b]) * dropmask  (b optional, broadcast over leading dim with period bmod: positional embedding)
 __global__ void dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t bmod,
                                float* __restrict__ out, int64_t n, uint64_t seed, const uint64_t* __restrict__ seed_dev,
@@ -44,16 +33,12 @@ __global__ void dropout_kernel(const float* __restrict__ a, const float* __restr
 
 __global__ void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   GRID_STRIDE(e, n) {
-    const float v = x[e];
-    y[e] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    y[e] = gelu_f(x[e]);
   }
 }
 __global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
   GRID_STRIDE(e, n) {
-    const float v = x[e];
-    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
-    dx[e] = dy[e] * (cdf + v * pdf);
+    dx[e] = dy[e] * gelu_grad_f(x[e]);
   }
 }
 __global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -129,13 +114,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx per row (wave per row) + per-block partial dgamma/dbeta (4 rows per block -> partial rows = gridDim.x)
+// Optional (myTransformerBlock backward): dres = gradient arriving over the residual connection, added to dx; dmasked =
+// dx * dropout mask of the branch below (seed / thresh / inv_keep), so neither a separate add nor a dropout pass runs.
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ stats, const float* __restrict__ dy,
-                                                            float* __restrict__ dx, int rows, int C) {
+                                                            float* __restrict__ dx, int rows, int C,
+                                                            const float* __restrict__ dres, float* __restrict__ dmasked,
+                                                            uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                            uint32_t thresh, float inv_keep) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (seed_dev != nullptr) seed += seed_dev[0];
   const float mean = stats[2 * row], rstd = stats[2 * row + 1];
   const float* xr = x + (int64_t)row * C;
   const float* dr = dy + (int64_t)row * C;
@@ -170,7 +161,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = rstd * (dg[i][k] - m1 - xh[i][k] * m2);
+      if (dres != nullptr) o += *reinterpret_cast<const f32x4*>(dres + (int64_t)row * C + c);
       *reinterpret_cast<f32x4*>(dxr + c) = o;
+      if (dmasked != nullptr) {
+        if (thresh) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] *= drop_scale(seed, (uint64_t)((int64_t)row * C + c + k), thresh, inv_keep);
+        }
+        *reinterpret_cast<f32x4*>(dmasked + (int64_t)row * C + c) = o;
+      }
     }
   }
 }
@@ -410,11 +409,6 @@ __global__ void seed_advance_kernel(uint64_t* seed) {
   seed[0] = z ^ (z >> 31);
 }
 
-inline uint32_t drop_thresh(float p) {
-  if (p <= 0.f) return 0u;
-  const double t = (double)p * 4294967296.0;
-  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-}
 
 template <typename F>
 int attn_dispatch(int dk, F&& f) {
@@ -483,16 +477,20 @@ extern "C" int mmi_layernorm_bwd_parts(int rows) {
   return p > 256 ? 256 : (p < 1 ? 1 : p);
 }
 
-extern "C" int mmi_layernorm_bwd(const float* x, const float* gamma, const float* stats, const float* dy, float* dx,
-                                 float* partials, float* dgamma, float* dbeta, int rows, int C, void* stream) {
-  MMI_CHECK_ARG(x && gamma && stats && dy && dx && partials && dgamma && dbeta && rows > 0, "mmi_layernorm_bwd: bad arguments");
-  MMI_CHECK_ARG(C % 4 == 0 && C <= 4096, "mmi_layernorm_bwd: C=%d must be a multiple of 4 and <= 4096", C);
+namespace {
+int ln_bwd_dx(const float* x, const float* gamma, const float* stats, const float* dy, float* dx, int rows, int C,
+              const float* dres, float* dmasked, float p, uint64_t seed, const uint64_t* seed_dev, hipStream_t s) {
   const dim3 grid(cdiv(rows, 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (C <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C);
-  else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C);
+  const uint32_t th = drop_thresh(p);
+  const float ik = 1.0f / (1.0f - p);
+  if (C <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C, dres, dmasked, seed, seed_dev, th, ik);
+  else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C, dres, dmasked, seed, seed_dev, th, ik);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, x, gamma, stats, dy, dx, rows, C, dres, dmasked, seed, seed_dev, th, ik);
   MMI_CHECK_LAUNCH("mmi_layernorm_bwd");
+  return MMI_OK;
+}
+int ln_bwd_params(const float* x, const float* stats, const float* dy, float* partials, float* dgamma, float* dbeta, int rows,
+                  int C, hipStream_t s) {
   const int nparts = mmi_layernorm_bwd_parts(rows);
   const int rpp = (rows + nparts - 1) / nparts;
   hipLaunchKernelGGL(layernorm_bwd_param_kernel, dim3(cdiv(C, 64), nparts), dim3(256), 0, s, x, stats, dy, partials, rows, C, rpp);
@@ -500,6 +498,30 @@ extern "C" int mmi_layernorm_bwd(const float* x, const float* gamma, const float
   hipLaunchKernelGGL(pair_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, partials, nparts, C, dbeta, dgamma);
   MMI_CHECK_LAUNCH("mmi_layernorm_bwd(finalize)");
   return MMI_OK;
+}
+}  // namespace
+
+extern "C" int mmi_layernorm_bwd(const float* x, const float* gamma, const float* stats, const float* dy, float* dx,
+                                 float* partials, float* dgamma, float* dbeta, int rows, int C, void* stream) {
+  MMI_CHECK_ARG(x && gamma && stats && dy && dx && partials && dgamma && dbeta && rows > 0, "mmi_layernorm_bwd: bad arguments");
+  MMI_CHECK_ARG(C % 4 == 0 && C <= 4096, "mmi_layernorm_bwd: C=%d must be a multiple of 4 and <= 4096", C);
+  if (int e = ln_bwd_dx(x, gamma, stats, dy, dx, rows, C, nullptr, nullptr, 0.f, 0, nullptr, (hipStream_t)stream)) return e;
+  return ln_bwd_params(x, stats, dy, partials, dgamma, dbeta, rows, C, (hipStream_t)stream);
+}
+
+extern "C" int mmi_layernorm_bwd_input(const float* x, const float* gamma, const float* stats, const float* dy,
+                                       const float* dresidual, float* dx, float* dx_dropped, float p_drop, uint64_t seed,
+                                       const uint64_t* seed_dev, int rows, int C, void* stream) {
+  MMI_CHECK_ARG(x && gamma && stats && dy && dx && rows > 0, "mmi_layernorm_bwd_input: bad arguments");
+  MMI_CHECK_ARG(C % 4 == 0 && C <= 4096, "mmi_layernorm_bwd_input: C=%d must be a multiple of 4 and <= 4096", C);
+  MMI_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed_dev != nullptr || seed != 0), "mmi_layernorm_bwd_input: bad dropout arguments");
+  return ln_bwd_dx(x, gamma, stats, dy, dx, rows, C, dresidual, dx_dropped, p_drop, seed, seed_dev, (hipStream_t)stream);
+}
+
+extern "C" int mmi_layernorm_bwd_params(const float* x, const float* stats, const float* dy, float* partials, float* dgamma,
+                                        float* dbeta, int rows, int C, void* stream) {
+  MMI_CHECK_ARG(x && stats && dy && partials && dgamma && dbeta && rows > 0 && C > 0, "mmi_layernorm_bwd_params: bad arguments");
+  return ln_bwd_params(x, stats, dy, partials, dgamma, dbeta, rows, C, (hipStream_t)stream);
 }
 
 extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out, float* probs, int B,

@@ -3,8 +3,9 @@
 import torch
 from torch.autograd import Function
 
-from . import lib
-from .ops import _nrows, _stream, grad_like, rows_of, scratch
+from . import lib, ops
+from .lib import (EPI_ACCUMULATE, EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_NONE, ConvDesc, LinearEpilogue)
+from .ops import _nrows, _stream, grad_like, rows_of, scratch, zeroed_scratch
 
 _drop_counter = [0]
 _seed_state = {}
@@ -207,6 +208,166 @@ class _Attention(Function):
 def attention(q, k, v, heads, p=0.0, training=True):
     p = float(p) if training else 0.0
     return _Attention.apply(q, k, v, heads, p, next_seed() if p > 0 else 0)
+
+
+def _linear_fwd(x, w, bias, y, rows, cin, cout, s, kind=EPI_NONE, aux=None, aux_out=None, p=0.0, seed=0, seed_dev=None):
+    """y = epilogue(x w^T + bias) over contiguous (rows, cin) -> (rows, cout): mmi_linear_fwd_fused."""
+    d = ConvDesc(rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, cin, cout)
+    nb = lib.conv_fwd_workspace(d)
+    ws = zeroed_scratch(nb, x.device, s) if nb else None
+    e = LinearEpilogue(kind, cout, cout, p, aux.data_ptr() if aux is not None else None,
+                       aux_out.data_ptr() if aux_out is not None else None, seed, seed_dev)
+    lib.linear_fwd_fused(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                         ws.data_ptr() if nb else None, nb, d, e, s)
+
+
+def _linear_dgrad(dy, w, dx, rows, cin, cout, s, kind=EPI_NONE, aux=None):
+    """dx = epilogue(dy w) over contiguous (rows, cout) -> (rows, cin): mmi_linear_dgrad_fused."""
+    d = ConvDesc(rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, cin, cout)
+    nb = lib.conv_dgrad_workspace(d)
+    ws = zeroed_scratch(nb, dy.device, s) if nb else None
+    e = LinearEpilogue(kind, cin, cin, 0.0, aux.data_ptr() if aux is not None else None, None, 0, None)
+    lib.linear_dgrad_fused(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, d, e, s)
+
+
+def _linear_wgrad(dy, x, w, bias, rows, cin, cout, need_w, need_b):
+    """(dw, dbias) of y = x w^T + bias on the weight-gradient side stream (ops._wgrad)."""
+    if not need_w:
+        db = None
+        if need_b:
+            db = grad_like(bias)
+            part = scratch(lib.bn_bwd_parts(rows) * cout, dy.device)
+            lib.colsum(dy.data_ptr(), cout, rows, cout, part.data_ptr(), db.data_ptr(), _stream())
+        return None, db
+    d = ConvDesc(rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, cin, cout)
+    if bias is not None and need_b:
+        return ops._wgrad(dy, cout, x, cin, w, d, overlap=ops.OVERLAP_WGRAD, want_bias=True, bias=bias)
+    return ops._wgrad(dy, cout, x, cin, w, d, overlap=ops.OVERLAP_WGRAD), None
+
+
+def _ln_param_grads(x, stats, dy, gamma, beta, rows, c):
+    """dgamma, dbeta: off the dependency chain, so they go where the weight gradients go."""
+    dg, db = grad_like(gamma), grad_like(beta)
+    nparts = lib.layernorm_bwd_parts(rows)
+    if ops.OVERLAP_WGRAD:
+        main, side = torch.cuda.current_stream(), ops._side_stream(x.device)
+        part = scratch(nparts * 2 * c, x.device, slot=5, stream=side.cuda_stream)
+        side.wait_stream(main)
+        lib.layernorm_bwd_params(x.data_ptr(), stats.data_ptr(), dy.data_ptr(), part.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                 rows, c, side.cuda_stream)
+        if ops.DEFER_JOIN:
+            ops._pending.append((x, stats, dy))
+            ops._pending_sides[side.cuda_stream] = side
+    else:
+        part = scratch(nparts * 2 * c, x.device)
+        lib.layernorm_bwd_params(x.data_ptr(), stats.data_ptr(), dy.data_ptr(), part.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                 rows, c, _stream())
+    return dg, db
+
+
+class _TransformerBlock(Function):
+    """myTransformerBlock (models/common.py:1237-1267 of the reference) as one autograd node:
+        x1 = x + drop(out_proj(attention(q, k, v)(ln_input(x))));  x2 = x1 + drop(mlp2(GELU(mlp0(ln_output(x1)))))
+    Forward 9 dependent kernels (LayerNorm, q/k/v, attention, out_proj+dropout+residual, LayerNorm, mlp0+GELU,
+    mlp2+dropout+residual), backward 11 on the chain; weight, bias and LayerNorm-parameter gradients run on the side stream.
+    The token chains are launch-latency bound (2048 rows x 128..1024 channels), so the kernel count is their cost."""
+
+    @staticmethod
+    def forward(ctx, x, heads, ps, eps, seeds, *params):
+        g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, g2, b2, w1, c1, w2, c2 = params
+        x = x.contiguous()
+        assert x.dim() == 3 and x.shape[1] == 128, 'the fusion transformers always see 2*8*8 = 128 tokens'
+        bsz, t, d = x.shape
+        rows, hid, dev, s = bsz * t, w1.shape[0], x.device, _stream()
+        sd = seed_state(dev).data_ptr() if max(ps) > 0 else None
+        new = lambda *shape: torch.empty(shape, dtype=x.dtype, device=dev)  # noqa: E731
+        ln1y, st1 = torch.empty_like(x), new(rows, 2)
+        lib.layernorm_fwd(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), ln1y.data_ptr(), st1.data_ptr(), rows, d, eps[0], s)
+        q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        for w, b, out in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):
+            _linear_fwd(ln1y, w, b, out, rows, d, d, s)
+        o, probs = torch.empty_like(x), new(bsz, heads, t, t)
+        lib.attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), probs.data_ptr(), bsz, heads, d // heads, d,
+                          ps[0], seeds[0], sd if ps[0] > 0 else None, s)
+        x1 = torch.empty_like(x)
+        _linear_fwd(o, wo, bo, x1, rows, d, d, s, EPI_DROPOUT_RESIDUAL, aux=x, p=ps[1], seed=seeds[1],
+                    seed_dev=sd if ps[1] > 0 else None)
+        ln2y, st2 = torch.empty_like(x), new(rows, 2)
+        lib.layernorm_fwd(x1.data_ptr(), g2.data_ptr(), b2.data_ptr(), ln2y.data_ptr(), st2.data_ptr(), rows, d, eps[1], s)
+        h, g = new(bsz, t, hid), new(bsz, t, hid)
+        _linear_fwd(ln2y, w1, c1, g, rows, d, hid, s, EPI_GELU, aux_out=h)
+        x2 = torch.empty_like(x)
+        _linear_fwd(g, w2, c2, x2, rows, hid, d, s, EPI_DROPOUT_RESIDUAL, aux=x1, p=ps[2], seed=seeds[2],
+                    seed_dev=sd if ps[2] > 0 else None)
+        ctx.save_for_backward(x, st1, ln1y, q, k, v, probs, o, x1, st2, ln2y, h, g, *params)
+        ctx.cfg = (heads, ps, seeds)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x, st1, ln1y, q, k, v, probs, o, x1, st2, ln2y, h, g = ctx.saved_tensors[:13]
+        g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, g2, b2, w1, c1, w2, c2 = ctx.saved_tensors[13:]
+        heads, ps, seeds = ctx.cfg
+        need = ctx.needs_input_grad[5:]
+        dx2 = dx2.contiguous()
+        bsz, t, d = x.shape
+        rows, hid, dev, s = bsz * t, w1.shape[0], x.device, _stream()
+        sd = seed_state(dev).data_ptr() if max(ps) > 0 else None
+        grads = [None] * 16
+
+        def wgrad(dy, inp, w, b, iw, cin, cout):
+            grads[iw], grads[iw + 1] = _linear_wgrad(dy, inp, w, b, rows, cin, cout, need[iw], need[iw + 1])
+
+        # ---- x2 = x1 + drop(mlp2(GELU(mlp0(ln_output(x1))))) ----
+        if ps[2] > 0:
+            dy2 = torch.empty_like(dx2)
+            lib.dropout(dx2.data_ptr(), None, 0, dy2.data_ptr(), dx2.numel(), ps[2], seeds[2], sd, s)
+        else:
+            dy2 = dx2
+        wgrad(dy2, g, w2, c2, 14, hid, d)
+        dh = torch.empty_like(h)
+        _linear_dgrad(dy2, w2, dh, rows, hid, d, s, EPI_GELU_GRAD, aux=h)
+        wgrad(dh, ln2y, w1, c1, 12, d, hid)
+        dln2 = torch.empty_like(x)
+        _linear_dgrad(dh, w1, dln2, rows, d, hid, s)
+        if need[10] or need[11]:
+            grads[10], grads[11] = _ln_param_grads(x1, st2, dln2, g2, b2, rows, d)
+        # dx1 = dx2 + LayerNorm'(dln2); dy1 = dx1 through the out_proj dropout mask
+        dx1 = torch.empty_like(x)
+        dy1 = torch.empty_like(x) if ps[1] > 0 else None
+        lib.layernorm_bwd_input(x1.data_ptr(), g2.data_ptr(), st2.data_ptr(), dln2.data_ptr(), dx2.data_ptr(), dx1.data_ptr(),
+                                dy1.data_ptr() if dy1 is not None else None, ps[1], seeds[1], sd if ps[1] > 0 else None,
+                                rows, d, s)
+        if dy1 is None:
+            dy1 = dx1
+        # ---- x1 = x + drop(out_proj(attention(ln_input(x)))) ----
+        wgrad(dy1, o, wo, bo, 8, d, d)
+        do = torch.empty_like(x)
+        _linear_dgrad(dy1, wo, do, rows, d, d, s)
+        dq, dk_, dv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
+                          dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, d, ps[0], seeds[0],
+                          sd if ps[0] > 0 else None, s)
+        dln1 = torch.empty_like(x)
+        for i, (dy, w, b) in enumerate(((dq, wq, bq), (dk_, wk, bk), (dv, wv, bv))):
+            wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d)
+            _linear_dgrad(dy, w, dln1, rows, d, d, s, EPI_ACCUMULATE if i else EPI_NONE, aux=dln1 if i else None)
+        if need[0] or need[1]:
+            grads[0], grads[1] = _ln_param_grads(x, st1, dln1, g1, b1, rows, d)
+        dx = torch.empty_like(x)
+        lib.layernorm_bwd_input(x.data_ptr(), g1.data_ptr(), st1.data_ptr(), dln1.data_ptr(), dx1.data_ptr(), dx.data_ptr(),
+                                None, 0.0, 0, None, rows, d, s)
+        if ops.OVERLAP_WGRAD:
+            ops._join_side(dev)            # (no-op in deferred-join mode: TrainStep joins once after backward)
+        return (dx, None, None, None, None, *grads)
+
+
+def transformer_block(x, heads, ps, eps, params, training=True):
+    """ps = (attention, out_proj, mlp) dropout probabilities; params in module order: ln_input (w, b), que/key/val/out_proj
+    (w, b each), ln_output (w, b), mlp[0] (w, b), mlp[2] (w, b)."""
+    ps = tuple(float(p) if training else 0.0 for p in ps)
+    seeds = tuple(next_seed() if p > 0 else 0 for p in ps)
+    return _TransformerBlock.apply(x, heads, ps, tuple(float(e) for e in eps), seeds, *params)
 
 
 class _PoolTokens(Function):

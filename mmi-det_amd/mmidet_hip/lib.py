@@ -24,6 +24,14 @@ class ConvDesc(Structure):
                                        'ldy')]
 
 
+class LinearEpilogue(Structure):
+    """mmi_linear_epilogue (include/mmidet_hip.h)."""
+    _fields_ = [('kind', c_int32), ('ldaux', c_int32), ('ldaux_out', c_int32), ('p_drop', c_float), ('aux', c_void_p),
+                ('aux_out', c_void_p), ('seed', c_uint64), ('seed_dev', c_void_p)]
+
+
+EPI_NONE, EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_ACCUMULATE = 0, 1, 2, 3, 4
+
 P = c_void_p
 _SIGS = {
     'mmi_version': (c_int, []),
@@ -39,6 +47,8 @@ _SIGS = {
     'mmi_nms_workspace': (c_size_t, [c_int, c_int64, c_int, c_int]),
     'mmi_nms': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, c_int, c_int, c_int, c_float, P, c_size_t, P, P,
                         P]),
+    'mmi_linear_fwd_fused': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), POINTER(LinearEpilogue), P]),
+    'mmi_linear_dgrad_fused': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), POINTER(LinearEpilogue), P]),
     'mmi_conv_dgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_dgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
@@ -74,6 +84,8 @@ _SIGS = {
     'mmi_layernorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     'mmi_layernorm_bwd_parts': (c_int, [c_int]),
     'mmi_layernorm_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    'mmi_layernorm_bwd_input': (c_int, [P, P, P, P, P, P, P, c_float, c_uint64, P, c_int, c_int, P]),
+    'mmi_layernorm_bwd_params': (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
     'mmi_attention_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
     'mmi_attention_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
     'mmi_avgpool8_fwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),

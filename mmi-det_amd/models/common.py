@@ -243,11 +243,14 @@ class myTransformerBlock(nn.Module):
                                  nn.Linear(block_exp * d_model, d_model), nn.Dropout(resid_pdrop))
 
     def forward(self, x):
-        li, lo = self.ln_input, self.ln_output
-        x = ops.add(x, self.sa(F2.layernorm(x, li.weight, li.bias, li.eps)))
-        hdn = F2.gelu(ops.linear(F2.layernorm(x, lo.weight, lo.bias, lo.eps), self.mlp[0].weight, self.mlp[0].bias))
-        y = ops.linear(hdn, self.mlp[2].weight, self.mlp[2].bias)
-        return ops.add(x, F2.dropout_add(y, None, self.mlp[3].p, self.training))
+        # one autograd node per block (mmidet_hip/fusion_ops.py:_TransformerBlock): dropout + residual add and GELU ride
+        # in the Linear epilogues, the residual gradient and the dropout mask in the LayerNorm backward
+        li, lo, sa = self.ln_input, self.ln_output, self.sa
+        params = (li.weight, li.bias, sa.que_proj.weight, sa.que_proj.bias, sa.key_proj.weight, sa.key_proj.bias,
+                  sa.val_proj.weight, sa.val_proj.bias, sa.out_proj.weight, sa.out_proj.bias, lo.weight, lo.bias,
+                  self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias)
+        return F2.transformer_block(x, sa.h, (sa.attn_drop.p, sa.resid_drop.p, self.mlp[3].p), (li.eps, lo.eps), params,
+                                    self.training)
 
 
 def _init_gpt(module):

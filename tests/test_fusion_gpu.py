@@ -214,3 +214,84 @@ def test_fusion_stats(B, H, W, C):
         assert abs(st[2] - ref[2]) < 1e-5 * abs(ref[2]), (st, ref)
     else:
         assert math.isnan(st[2]) and math.isnan(ref[2])                       # reference quirk at B=1
+
+
+def _block_params(blk):
+    sa = blk.sa
+    return (blk.ln_input.weight, blk.ln_input.bias, sa.que_proj.weight, sa.que_proj.bias, sa.key_proj.weight,
+            sa.key_proj.bias, sa.val_proj.weight, sa.val_proj.bias, sa.out_proj.weight, sa.out_proj.bias,
+            blk.ln_output.weight, blk.ln_output.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias)
+
+
+@pytest.mark.parametrize('B,C', [(2, 128), (16, 256), (3, 512), (16, 1024), (1, 160)])
+def test_transformer_block_matches_oracle(B, C):
+    """myTransformerBlock (models/common.py:1237-1267) as one fused autograd node against the oracle's module: output,
+    input gradient and the 16 parameter gradients.  (16, 256) and (16, 1024) are bench shapes (stream-K schedules)."""
+    import models.common as mc
+    from oracle import ref_model as R
+    torch.manual_seed(C + B)
+    ref = R.myTransformerBlock(C, C, C, 8, 4, 0.0, 0.0)
+    for p in ref.parameters():                       # default Linear init leaves tiny biases; make every term count
+        p.data.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(B, 128, C)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    go = torch.randn_like(yr)
+    yr.backward(go)
+    d = dev()
+    blk = mc.myTransformerBlock(C, C, C, 8, 4, 0.0, 0.0)
+    blk.load_state_dict(ref.state_dict())
+    blk.to(d).train()
+    xg = x.to(d).requires_grad_()
+    yg = blk(xg)
+    yg.backward(go.to(d))
+    torch.cuda.synchronize()
+    close(yg, yr, what='out')
+    close(xg.grad, xr.grad, tol=2e-3, what="dx")
+    scale = float(ref.sa.que_proj.bias.grad.abs().max())
+    for (n, pr), pg in zip(ref.named_parameters(), blk.parameters()):
+        if n == 'sa.key_proj.bias':     # softmax is invariant to a key bias: the true gradient is 0, both sides hold rounding noise
+            assert float(pg.grad.abs().max()) < 1e-3 * scale and float(pr.grad.abs().max()) < 1e-3 * scale
+            continue
+        close(pg.grad, pr.grad, tol=2e-3, what=n)
+
+
+def test_transformer_block_dropout_matches_unfused_kernels():
+    """With dropout the fused node must draw the masks the separate kernels draw from the same salts (same hash, same
+    element index) and use them again in the backward: compare with the block composed of the single-op kernels."""
+    import models.common as mc
+    from mmidet_hip import fusion_ops as F2
+    from mmidet_hip import ops
+    d = dev()
+    torch.manual_seed(5)
+    B, C, heads = 4, 256, 8
+    blk = mc.myTransformerBlock(C, C, C, heads, 4, 0.1, 0.1).to(d).train()
+    for p in blk.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(B, 128, C, device=d)
+    go = torch.randn(B, 128, C, device=d)
+    ps, seeds, eps = (0.1, 0.2, 0.3), (11, 222, 3333), (1e-5, 1e-5)
+    prm = _block_params(blk)
+
+    xf = x.clone().requires_grad_()
+    yf = F2._TransformerBlock.apply(xf, heads, ps, eps, seeds, *prm)
+    yf.backward(go)
+    fused = [xf.grad.clone()] + [p.grad.clone() for p in prm]
+    for p in prm:
+        p.grad = None
+
+    xu = x.clone().requires_grad_()
+    g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, g2, b2, w1, c1, w2, c2 = prm
+    ln = F2.layernorm(xu, g1, b1, eps[0])
+    att = F2._Attention.apply(ops.linear(ln, wq, bq), ops.linear(ln, wk, bk), ops.linear(ln, wv, bv), heads, ps[0], seeds[0])
+    x1 = ops.add(xu, F2._DropoutAdd.apply(ops.linear(att, wo, bo), None, ps[1], seeds[1]))
+    hdn = F2.gelu(ops.linear(F2.layernorm(x1, g2, b2, eps[1]), w1, c1))
+    yu = ops.add(x1, F2._DropoutAdd.apply(ops.linear(hdn, w2, c2), None, ps[2], seeds[2]))
+    yu.backward(go)
+    torch.cuda.synchronize()
+    assert (yf == 0).float().mean() < 0.01 and not torch.equal(yf, x)
+    close(yf, yu, tol=1e-5, what="out")
+    names = ['dx', 'ln1.w', 'ln1.b', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'wo', 'bo', 'ln2.w', 'ln2.b', 'w1', 'b1', 'w2', 'b2']
+    for n, a, b in zip(names, fused, [xu.grad] + [p.grad for p in prm]):
+        if n != 'bk':                   # (true gradient 0, see above)
+            close(a, b, tol=1e-4, what=n)
