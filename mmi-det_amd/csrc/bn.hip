@@ -10,8 +10,8 @@ namespace {
 
 // Sum partial rows [blockIdx.y*chunk, +chunk) of partials[part][2][C] in fp64: one block = 16 channels x 16 part-lanes
 // (64-byte channel segments stay coalesced, a long part list is walked 16-wide).  Result in red[s][0][cl] of warp 0.
-__device__ __forceinline__ void fold_parts(const float* __restrict__ partials, int p0, int p1, int C, int c, int cl, int pl,
-                                           double (*red)[16][16], double& s1, double& s2) {
+__device__ __forceinline__ void fold_parts(const float* partials, int p0, int p1, int C, int c, int cl, int pl,
+                                           double (*red)[16][16], double& s1, double& s2, int64_t pstride = 1) {
   s1 = s2 = 0.0;
   if (c < C) {
     constexpr int U = 16;  // loads of one round are independent: a 1024-part list costs 4 memory latencies, not 64
@@ -21,8 +21,8 @@ __device__ __forceinline__ void fold_parts(const float* __restrict__ partials, i
       for (int u = 0; u < U; ++u) {
         const int pp = p + 16 * u;
         const bool ok = pp < p1;
-        a[u] = ok ? partials[((int64_t)pp * 2 + 0) * C + c] : 0.0f;
-        b[u] = ok ? partials[((int64_t)pp * 2 + 1) * C + c] : 0.0f;
+        a[u] = ok ? partials[((int64_t)pp * pstride * 2 + 0) * C + c] : 0.0f;
+        b[u] = ok ? partials[((int64_t)pp * pstride * 2 + 1) * C + c] : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -251,14 +251,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_narrow_kernel(const float* 
   }
 }
 
-// partials -> dbeta (= sum dz), dgamma (= sum dz*xhat)
+// stage 1 for very long part lists, in place: block y folds rows [y*chunk, (y+1)*chunk) into row y*chunk (read by nobody else)
+__global__ void pair_fold_inplace_kernel(float* partials, int nparts, int C, int chunk) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int p0 = blockIdx.y * chunk, p1 = min(p0 + chunk, nparts);
+  double s1, s2;
+  fold_parts(partials, p0, p1, C, c, cl, pl, red, s1, s2);  // ends with every read done (barrier inside)
+  if (pl == 0 && c < C && p0 < nparts) {
+    partials[((int64_t)p0 * 2 + 0) * C + c] = (float)s1;
+    partials[((int64_t)p0 * 2 + 1) * C + c] = (float)s2;
+  }
+}
+
+// partials -> dbeta (= sum dz), dgamma (= sum dz*xhat); pstride: row stride of the list (after an in-place stage 1)
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nparts, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+                                       float* __restrict__ dbeta, int pstride) {
   __shared__ double red[2][16][16];
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s1, s2;
-  fold_parts(partials, 0, nparts, C, c, cl, pl, red, s1, s2);
+  fold_parts(partials, 0, nparts, C, c, cl, pl, red, s1, s2, pstride);
   if (pl == 0 && c < C) {
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
@@ -452,7 +466,7 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && dy && dgamma && dbeta && rows > 0 && C > 0,
                 "mmi_bn_act_bwd_apply: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
   const bool vec = vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta});
   bool fixed;
@@ -481,11 +495,21 @@ extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* p
   return MMI_OK;
 }
 
-// library-internal (common.h): partials[part][2][C] -> out0 = sum of slot 0, out1 = sum of slot 1, folded in fp64
-int mmi_pair_colsum(const float* partials, int nparts, int C, float* out0, float* out1, void* stream) {
+// library-internal (common.h): partials[part][2][C] -> out0 = sum of slot 0, out1 = sum of slot 1, folded in fp64.  Lists
+// longer than 1024 parts (the CEM stencil backward: one part per 256 full-resolution pixels) are first folded 128-wide IN
+// PLACE, so the caller's partials are consumed.
+int mmi_pair_colsum(float* partials, int nparts, int C, float* out0, float* out1, void* stream) {
   MMI_CHECK_ARG(partials && out0 && out1 && nparts > 0 && C > 0, "mmi_pair_colsum: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials, nparts, C, out1,
-                     out0);
+  hipStream_t s = (hipStream_t)stream;
+  int pstride = 1;
+  if (nparts > 1024) {
+    const int chunk = cdiv(nparts, 128);
+    hipLaunchKernelGGL(pair_fold_inplace_kernel, dim3(cdiv(C, 16), cdiv(nparts, chunk)), dim3(256), 0, s, partials, nparts, C, chunk);
+    MMI_CHECK_LAUNCH("mmi_pair_colsum(fold)");
+    pstride = chunk;
+    nparts = cdiv(nparts, chunk);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, out1, out0, pstride);
   MMI_CHECK_LAUNCH("mmi_pair_colsum");
   return MMI_OK;
 }
