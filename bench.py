@@ -91,8 +91,9 @@ class ConvTimer:
         from mmidet_hip import lib
         timer = self
 
-        def wrap(name, flops_of):
+        def wrap(name, flops_of, label=None):
             fn = getattr(lib, name)
+            attr, name = name, label or name
 
             def timed(*a):
                 if not timer.on:
@@ -106,7 +107,7 @@ class ConvTimer:
                 dd = [x for x in a if hasattr(x, 'Cout')][0]
                 timer.shapes.append((dd.N, dd.H, dd.W, dd.Cin, dd.Cout, dd.KH, dd.stride))
                 return r
-            setattr(lib, name, timed)
+            setattr(lib, attr, timed)
 
         def fl(d):
             return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW
@@ -115,6 +116,9 @@ class ConvTimer:
         wrap('conv_fwd', lambda a: fl(desc_of(a)))
         wrap('conv_dgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad', lambda a: fl(desc_of(a)))
+        # the transformer blocks' Linear layers with fused epilogues (same kernels, counted with the convolutions)
+        wrap('linear_fwd_fused', lambda a: fl(desc_of(a)), 'conv_fwd')
+        wrap('linear_dgrad_fused', lambda a: fl(desc_of(a)), 'conv_dgrad')
 
     def by_shape(self):
         """[(entry point, shape) -> launches, ms, TFLOP/s] sorted by time: where the GEMM time goes."""
