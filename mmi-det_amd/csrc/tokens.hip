@@ -402,6 +402,254 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- MFMA attention (head dims that are multiples of 8) ---------------------------------------------------------------
+// The same five 128 x 128 x DK products on v_mfma_f32_32x32x2_f32 (exact fp32 products, as everywhere on this path).  One
+// workgroup per (batch, head), wave w owns query rows (or, for dK / dV, key rows) [32w, 32w+32).  Operand conventions of the
+// instruction: A lane l holds A[m = l&31][k = l>>5], B lane l holds B[k = l>>5][n = l&31]; a lane that reads four
+// consecutive k of its row as one f32x4 at k0 = 8g + 4(l>>5) feeds four MFMAs (element e contracts k0 + e on both sides).
+//   row-major operands ("[row][k]", contraction along the row: Q, K in QK^T; dO, V in dO V^T; P, dS along the keys) are read
+//   as ds_read_b128 from a buffer whose row stride is DKP+4 (or T+4) floats = an odd number of 16-byte groups;
+//   column operands ("[k][col]": V in PV, K in dS K, Q in dS^T Q, dO in P^T dO, and the transposed dS / P) as ds_read_b32
+//   of 32 consecutive floats.
+// The A operand of the first product (Q, dO) never touches LDS: each lane loads its own fragments from global memory.
+constexpr int PSM = T + 4;
+
+__device__ __forceinline__ int mfma_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }  // C/D layout of 32x32
+__device__ __forceinline__ float half_wave_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int DK>
+struct AttnGeom {
+  static constexpr int DKP = (DK + 31) / 32 * 32;  // columns of the [T][DK] operand tile, zero padded to whole MFMA tiles
+  static constexpr int RS = DKP + 4;               // its row stride in floats
+  static constexpr int NG = DK / 8;                // 8-k groups along the head dimension
+  static constexpr int CT = DKP / 32;              // 32-column tiles of a [T][DK] result
+};
+
+// [T][DK] rows of one (batch, head) -> OP[row][RS], columns DK..DKP zeroed
+template <int DK>
+__device__ __forceinline__ void attn_stage(float* OP, const float* __restrict__ src, int64_t base, int ld, int t) {
+  using G = AttnGeom<DK>;
+  constexpr int V4 = G::DKP / 4;
+  for (int e = t; e < T * V4; e += 256) {
+    const int row = e / V4, c4 = e - row * V4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < DK) v = *reinterpret_cast<const f32x4*>(src + base + (int64_t)row * ld + c4 * 4);
+    *reinterpret_cast<f32x4*>(OP + row * G::RS + c4 * 4) = v;
+  }
+}
+
+// acc[jt] (+)= A_frag . rowmajor(OP)^T : 32 rows of this wave x 128 columns (rows of OP), contraction over DK
+template <int DK>
+__device__ __forceinline__ void attn_rows_times_rowsT(const f32x4 (&af)[AttnGeom<DK>::NG], const float* OP, int l31, int lh,
+                                                      f32x16 (&acc)[4]) {
+  using G = AttnGeom<DK>;
+#pragma unroll
+  for (int g = 0; g < G::NG; ++g) {
+    f32x4 b[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) b[jt] = *reinterpret_cast<const f32x4*>(OP + (jt * 32 + l31) * G::RS + g * 8 + lh * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][e], b[jt][e], acc[jt], 0, 0, 0);
+  }
+}
+
+// o[ct] = S-operand x OP : 32 result rows of this wave x DKP columns, contraction over the 128 rows of OP.
+// TRANS = false: A[m][k] = S[(32w + m) * PSM + k]  (P V, dS K);  TRANS = true: A[m][k] = S[k * PSM + 32w + m]  (dS^T Q, P^T dO)
+template <int DK, bool TRANS>
+__device__ __forceinline__ void attn_scores_times_cols(const float* S, const float* OP, int w, int l31, int lh,
+                                                       f32x16 (&o)[AttnGeom<DK>::CT]) {
+  using G = AttnGeom<DK>;
+#pragma unroll
+  for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+#pragma unroll 4
+  for (int g = 0; g < T / 8; ++g) {
+    f32x4 a;
+    if (!TRANS) {
+      a = *reinterpret_cast<const f32x4*>(S + (32 * w + l31) * PSM + g * 8 + lh * 4);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = S[(g * 8 + lh * 4 + e) * PSM + 32 * w + l31];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* brow = OP + (g * 8 + lh * 4 + e) * G::RS + l31;
+#pragma unroll
+      for (int ct = 0; ct < G::CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], brow[ct * 32], o[ct], 0, 0, 0);
+    }
+  }
+}
+
+template <int DK>
+__device__ __forceinline__ void attn_store_rows(float* __restrict__ dst, int64_t base, int ld, int w, int l31, int lh,
+                                                const f32x16 (&o)[AttnGeom<DK>::CT]) {
+#pragma unroll
+  for (int ct = 0; ct < AttnGeom<DK>::CT; ++ct) {
+    const int col = ct * 32 + l31;
+    if (col < DK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[base + (int64_t)(32 * w + mfma_row(r, lh)) * ld + col] = o[ct][r];
+    }
+  }
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ out,
+                                                            float* __restrict__ probs, int ld, int heads, float scale,
+                                                            uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                            uint32_t thresh, float inv_keep) {
+  using G = AttnGeom<DK>;
+  __shared__ __align__(16) float sm[T * G::RS + T * PSM];
+  if (seed_dev != nullptr) seed += seed_dev[0];
+  float* OP = sm;
+  float* P = sm + T * G::RS;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * T * ld + (int64_t)h * DK;
+  f32x4 qa[G::NG];
+#pragma unroll
+  for (int g = 0; g < G::NG; ++g) qa[g] = *reinterpret_cast<const f32x4*>(q + base + (int64_t)(32 * w + l31) * ld + g * 8 + lh * 4);
+  attn_stage<DK>(OP, k, base, ld, t);
+  __syncthreads();
+  f32x16 acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+  attn_rows_times_rowsT<DK>(qa, OP, l31, lh, acc);
+  // softmax over the 128 keys of a row: 4 column tiles in this lane x the 32 lanes of its half wave
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * w + mfma_row(r, lh);
+    float sv[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      sv[jt] = acc[jt][r] * scale;
+      m = fmaxf(m, sv[jt]);
+    }
+    m = half_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      sv[jt] = expf(sv[jt] - m);
+      sum += sv[jt];
+    }
+    const float inv = 1.0f / half_wave_sum(sum);
+    float* prow = probs + ((int64_t)bh * T + row) * T;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int j = jt * 32 + l31;
+      const float pv = sv[jt] * inv;
+      prow[j] = pv;  // saved softmax (pre-dropout) for the backward pass
+      P[row * PSM + j] = thresh ? pv * drop_scale(seed, (uint64_t)(((int64_t)bh * T + row) * T + j), thresh, inv_keep) : pv;
+    }
+  }
+  __syncthreads();  // every wave is done with K; P complete
+  attn_stage<DK>(OP, v, base, ld, t);
+  __syncthreads();
+  f32x16 o[G::CT];
+  attn_scores_times_cols<DK, false>(P, OP, w, l31, lh, o);
+  attn_store_rows<DK>(out, base, ld, w, l31, lh, o);
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ probs,
+                                                            const float* __restrict__ dout, float* __restrict__ dq,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int ld, int heads,
+                                                            float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                            uint32_t thresh, float inv_keep) {
+  using G = AttnGeom<DK>;
+  __shared__ __align__(16) float sm[T * G::RS + T * PSM];
+  if (seed_dev != nullptr) seed += seed_dev[0];
+  float* OP = sm;
+  float* S = sm + T * G::RS;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * T * ld + (int64_t)h * DK;
+
+  // phase 1: dP'[r][j] = <dO[r], V[j]>;  dS = P * (dP - sum_j dP*P) / sqrt(dk),  dP = dP' * mask/(1-p)
+  {
+    f32x4 da[G::NG];
+#pragma unroll
+    for (int g = 0; g < G::NG; ++g)
+      da[g] = *reinterpret_cast<const f32x4*>(dout + base + (int64_t)(32 * w + l31) * ld + g * 8 + lh * 4);
+    attn_stage<DK>(OP, v, base, ld, t);
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    attn_rows_times_rowsT<DK>(da, OP, l31, lh, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * w + mfma_row(r, lh);
+      const float* prow = probs + ((int64_t)bh * T + row) * T;
+      float pv[4], dp[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int j = jt * 32 + l31;
+        pv[jt] = prow[j];
+        dp[jt] = acc[jt][r];
+        if (thresh) dp[jt] *= drop_scale(seed, (uint64_t)(((int64_t)bh * T + row) * T + j), thresh, inv_keep);
+        dot += dp[jt] * pv[jt];
+      }
+      dot = half_wave_sum(dot);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) S[row * PSM + jt * 32 + l31] = pv[jt] * (dp[jt] - dot) * scale;
+    }
+  }
+  __syncthreads();  // V consumed, dS complete (phase 3 reads every row of it)
+
+  f32x16 o[G::CT];
+  // phase 2: dQ[r] = sum_j dS[r][j] K[j]
+  attn_stage<DK>(OP, k, base, ld, t);
+  __syncthreads();
+  attn_scores_times_cols<DK, false>(S, OP, w, l31, lh, o);
+  attn_store_rows<DK>(dq, base, ld, w, l31, lh, o);
+  __syncthreads();
+
+  // phase 3: dK[j] = sum_r dS[r][j] Q[r]   (wave w owns keys 32w..32w+31)
+  attn_stage<DK>(OP, q, base, ld, t);
+  __syncthreads();
+  attn_scores_times_cols<DK, true>(S, OP, w, l31, lh, o);
+  attn_store_rows<DK>(dk, base, ld, w, l31, lh, o);
+  __syncthreads();  // dS and Q consumed
+
+  // phase 4: dV[j] = sum_r P'[r][j] dO[r],  P' = P * mask/(1-p)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * w + mfma_row(r, lh);
+    const float* prow = probs + ((int64_t)bh * T + row) * T;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int j = jt * 32 + l31;
+      const float pv = prow[j];
+      S[row * PSM + j] = thresh ? pv * drop_scale(seed, (uint64_t)(((int64_t)bh * T + row) * T + j), thresh, inv_keep) : pv;
+    }
+  }
+  attn_stage<DK>(OP, dout, base, ld, t);
+  __syncthreads();
+  attn_scores_times_cols<DK, true>(S, OP, w, l31, lh, o);
+  attn_store_rows<DK>(dv, base, ld, w, l31, lh, o);
+}
+
 __global__ void seed_advance_kernel(uint64_t* seed) {
   uint64_t z = seed[0] + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -534,7 +782,10 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
   hipStream_t s = (hipStream_t)stream;
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
-    hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
+    if constexpr (DK % 8 == 0)
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
+    else
+      hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
     return 0;
   });
   MMI_CHECK_ARG(rc == 0, "mmi_attention_fwd: head dim %d unsupported (4,8,16,20,32,40,64,80,128,160)", dk);
@@ -553,8 +804,12 @@ extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v,
   hipStream_t s = (hipStream_t)stream;
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
-    hipLaunchKernelGGL(attn_bwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads, scale,
-                       seed, seed_dev, th, ik);
+    if constexpr (DK % 8 == 0)
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads,
+                         scale, seed, seed_dev, th, ik);
+    else
+      hipLaunchKernelGGL(attn_bwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads, scale,
+                         seed, seed_dev, th, ik);
     return 0;
   });
   MMI_CHECK_ARG(rc == 0, "mmi_attention_bwd: head dim %d unsupported (4,8,16,20,32,40,64,80,128,160)", dk);
