@@ -222,6 +222,13 @@ int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out
 int mmi_attention_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout, float* dq,
                       float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop, uint64_t seed,
                       const uint64_t* seed_dev, void* stream);
+/* The same with two row strides: ld for q, k, v (and dq, dk, dv), ldo for out (and dout).  q, k, v may then be the three
+ * column blocks of one (B*128, 3*heads*dk) buffer written by a single packed projection GEMM. */
+int mmi_attention_fwd_strided(const float* q, const float* k, const float* v, float* out, float* probs, int B, int heads,
+                              int dk, int ld, int ldo, float p_drop, uint64_t seed, const uint64_t* seed_dev, void* stream);
+int mmi_attention_bwd_strided(const float* q, const float* k, const float* v, const float* probs, const float* dout,
+                              float* dq, float* dk_, float* dv, int B, int heads, int dk, int ld, int ldo, float p_drop,
+                              uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* ---- fusion stack, spatial side ------------------------------------------------------------------------------------ */
 /* nn.AdaptiveAvgPool2d((8,8)) (common.py:395-396, 1331-1332) written straight into the token layout:

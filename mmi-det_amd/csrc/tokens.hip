@@ -218,7 +218,7 @@ constexpr int PS = T + 1;  // padded row stride of the score matrix in LDS
 template <int DK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ out,
-                                                       float* __restrict__ probs, int ld, int heads, float scale,
+                                                       float* __restrict__ probs, int ld, int ldo, int heads, float scale,
                                                        uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                        uint32_t thresh, float inv_keep) {
   __shared__ __align__(16) float sm[T * DK + T * PS];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int i = 0; i < (SPLIT ? HV : DV); ++i)
-      *reinterpret_cast<f32x4*>(out + base + (int64_t)r * ld + c0 + i * 4) = acc[i];
+      *reinterpret_cast<f32x4*>(out + (int64_t)b * T * ldo + (int64_t)h * DK + (int64_t)r * ldo + c0 + i * 4) = acc[i];
   }
 }
 
@@ -297,7 +297,7 @@ template <int DK>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ probs,
                                                        const float* __restrict__ dout, float* __restrict__ dq,
-                                                       float* __restrict__ dk, float* __restrict__ dv, int ld, int heads,
+                                                       float* __restrict__ dk, float* __restrict__ dv, int ld, int ldo, int heads,
                                                        float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                        uint32_t thresh, float inv_keep) {
   __shared__ __align__(16) float sm[T * DK + T * PS];
@@ -311,19 +311,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   constexpr bool SPLIT = DK % 8 == 0;
   constexpr int HV = SPLIT ? (DK / 2) / 4 : DV;
   const int c0 = SPLIT ? hf * (DK / 2) : 0;
-  auto stage = [&](const float* src) {
+  const int64_t base_o = (int64_t)b * T * ldo + (int64_t)h * DK;  // dout has its own row stride
+  auto stage = [&](const float* src, int64_t sbase, int sld) {
     for (int e = t; e < T * DV; e += 256) {
       const int row = e / DV, c4 = e - row * DV;
-      *reinterpret_cast<f32x4*>(OP + row * DK + c4 * 4) = *reinterpret_cast<const f32x4*>(src + base + (int64_t)row * ld + c4 * 4);
+      *reinterpret_cast<f32x4*>(OP + row * DK + c4 * 4) = *reinterpret_cast<const f32x4*>(src + sbase + (int64_t)row * sld + c4 * 4);
     }
   };
   const float* prow = probs + ((int64_t)bh * T + r) * T;
 
   // phase 1: dP'[r][j] = <dO[r], V[j]>;  dS = P * (dP - sum_j dP*P),  dP = dP' * mask/(1-p)
-  stage(v);
+  stage(v, base, ld);
   f32x4 dor[DV];
 #pragma unroll
-  for (int i = 0; i < DV; ++i) dor[i] = *reinterpret_cast<const f32x4*>(dout + base + (int64_t)r * ld + i * 4);
+  for (int i = 0; i < DV; ++i) dor[i] = *reinterpret_cast<const f32x4*>(dout + base_o + (int64_t)r * ldo + i * 4);
   __syncthreads();
   float dot = 0.f;
   for (int jj = 0; jj < T / 2; ++jj) {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   __syncthreads();
 
   // phase 2: dQ[r] = sum_j dS[r][j] K[j]
-  stage(k);
+  stage(k, base, ld);
   __syncthreads();
   if (SPLIT || hf == 0) {
     f32x4 acc[HV];
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   __syncthreads();
 
   // phase 3: dK[j] = sum_r dS[r][j] Q[r]   (thread pair owns key row j = r)
-  stage(q);
+  stage(q, base, ld);
   __syncthreads();
   if (SPLIT || hf == 0) {
     f32x4 acc[HV];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float p = prow[j];
     S[r * PS + j] = thresh ? p * drop_scale(seed, (uint64_t)(((int64_t)bh * T + r) * T + j), thresh, inv_keep) : p;
   }
-  stage(dout);
+  stage(dout, base_o, ldo);
   __syncthreads();
   if (SPLIT || hf == 0) {
     f32x4 acc[HV];
@@ -508,7 +509,7 @@ __device__ __forceinline__ void attn_store_rows(float* __restrict__ dst, int64_t
 template <int DK>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ out,
-                                                            float* __restrict__ probs, int ld, int heads, float scale,
+                                                            float* __restrict__ probs, int ld, int ldo, int heads, float scale,
                                                             uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                             uint32_t thresh, float inv_keep) {
   using G = AttnGeom<DK>;
@@ -563,14 +564,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
   __syncthreads();
   f32x16 o[G::CT];
   attn_scores_times_cols<DK, false>(P, OP, w, l31, lh, o);
-  attn_store_rows<DK>(out, base, ld, w, l31, lh, o);
+  attn_store_rows<DK>(out, (int64_t)b * T * ldo + (int64_t)h * DK, ldo, w, l31, lh, o);
 }
 
 template <int DK>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, const float* __restrict__ probs,
                                                             const float* __restrict__ dout, float* __restrict__ dq,
-                                                            float* __restrict__ dk, float* __restrict__ dv, int ld, int heads,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int ld, int ldo, int heads,
                                                             float scale, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                             uint32_t thresh, float inv_keep) {
   using G = AttnGeom<DK>;
@@ -581,13 +582,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * T * ld + (int64_t)h * DK;
+  const int64_t base_o = (int64_t)b * T * ldo + (int64_t)h * DK;  // dout has its own row stride
 
   // phase 1: dP'[r][j] = <dO[r], V[j]>;  dS = P * (dP - sum_j dP*P) / sqrt(dk),  dP = dP' * mask/(1-p)
   {
     f32x4 da[G::NG];
 #pragma unroll
     for (int g = 0; g < G::NG; ++g)
-      da[g] = *reinterpret_cast<const f32x4*>(dout + base + (int64_t)(32 * w + l31) * ld + g * 8 + lh * 4);
+      da[g] = *reinterpret_cast<const f32x4*>(dout + base_o + (int64_t)(32 * w + l31) * ldo + g * 8 + lh * 4);
     attn_stage<DK>(OP, v, base, ld, t);
     __syncthreads();
     f32x16 acc[4];
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
       S[row * PSM + j] = thresh ? pv * drop_scale(seed, (uint64_t)(((int64_t)bh * T + row) * T + j), thresh, inv_keep) : pv;
     }
   }
-  attn_stage<DK>(OP, dout, base, ld, t);
+  attn_stage<DK>(OP, dout, base_o, ldo, t);
   __syncthreads();
   attn_scores_times_cols<DK, true>(S, OP, w, l31, lh, o);
   attn_store_rows<DK>(dv, base, ld, w, l31, lh, o);
@@ -775,7 +777,15 @@ extern "C" int mmi_layernorm_bwd_params(const float* x, const float* stats, cons
 extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v, float* out, float* probs, int B,
                                  int heads, int dk, int ld, float p_drop, uint64_t seed, const uint64_t* seed_dev,
                                  void* stream) {
-  MMI_CHECK_ARG(q && k && v && out && probs && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0, "mmi_attention_fwd: bad arguments");
+  return mmi_attention_fwd_strided(q, k, v, out, probs, B, heads, dk, ld, ld, p_drop, seed, seed_dev, stream);
+}
+
+extern "C" int mmi_attention_fwd_strided(const float* q, const float* k, const float* v, float* out, float* probs, int B,
+                                         int heads, int dk, int ld, int ldo, float p_drop, uint64_t seed,
+                                         const uint64_t* seed_dev, void* stream) {
+  MMI_CHECK_ARG(q && k && v && out && probs && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0 && ldo >= heads * dk && ldo % 4 == 0,
+                "mmi_attention_fwd: bad arguments");
+  MMI_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "mmi_attention_fwd: operands must be 16-byte aligned");
   const float scale = 1.0f / sqrtf((float)dk);
   const uint32_t th = drop_thresh(p_drop);
   const float ik = 1.0f / (1.0f - p_drop);
@@ -783,9 +793,9 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
     if constexpr (DK % 8 == 0)
-      hipLaunchKernelGGL(attn_fwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
+      hipLaunchKernelGGL(attn_fwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, ldo, heads, scale, seed, seed_dev, th, ik);
     else
-      hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, heads, scale, seed, seed_dev, th, ik);
+      hipLaunchKernelGGL(attn_fwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, out, probs, ld, ldo, heads, scale, seed, seed_dev, th, ik);
     return 0;
   });
   MMI_CHECK_ARG(rc == 0, "mmi_attention_fwd: head dim %d unsupported (4,8,16,20,32,40,64,80,128,160)", dk);
@@ -796,8 +806,18 @@ extern "C" int mmi_attention_fwd(const float* q, const float* k, const float* v,
 extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v, const float* probs, const float* dout,
                                  float* dq, float* dk_, float* dv, int B, int heads, int dk, int ld, float p_drop,
                                  uint64_t seed, const uint64_t* seed_dev, void* stream) {
-  MMI_CHECK_ARG(q && k && v && probs && dout && dq && dk_ && dv && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0,
+  return mmi_attention_bwd_strided(q, k, v, probs, dout, dq, dk_, dv, B, heads, dk, ld, ld, p_drop, seed, seed_dev, stream);
+}
+
+extern "C" int mmi_attention_bwd_strided(const float* q, const float* k, const float* v, const float* probs,
+                                         const float* dout, float* dq, float* dk_, float* dv, int B, int heads, int dk,
+                                         int ld, int ldo, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                                         void* stream) {
+  MMI_CHECK_ARG(q && k && v && probs && dout && dq && dk_ && dv && B > 0 && heads > 0 && ld >= heads * dk && ld % 4 == 0 &&
+                    ldo >= heads * dk && ldo % 4 == 0,
                 "mmi_attention_bwd: bad arguments");
+  MMI_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk_ | (uintptr_t)dv) & 15) == 0,
+                "mmi_attention_bwd: operands must be 16-byte aligned");
   const float scale = 1.0f / sqrtf((float)dk);
   const uint32_t th = drop_thresh(p_drop);
   const float ik = 1.0f / (1.0f - p_drop);
@@ -805,10 +825,10 @@ extern "C" int mmi_attention_bwd(const float* q, const float* k, const float* v,
   const int rc = attn_dispatch(dk, [&](auto DKc) {
     constexpr int DK = decltype(DKc)::value;
     if constexpr (DK % 8 == 0)
-      hipLaunchKernelGGL(attn_bwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads,
-                         scale, seed, seed_dev, th, ik);
+      hipLaunchKernelGGL(attn_bwd_mfma_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, ldo,
+                         heads, scale, seed, seed_dev, th, ik);
     else
-      hipLaunchKernelGGL(attn_bwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, heads, scale,
+      hipLaunchKernelGGL(attn_bwd_kernel<DK>, dim3(B * heads), dim3(256), 0, s, q, k, v, probs, dout, dq, dk_, dv, ld, ldo, heads, scale,
                          seed, seed_dev, th, ik);
     return 0;
   });

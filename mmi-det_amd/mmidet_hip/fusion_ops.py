@@ -230,19 +230,53 @@ def _linear_dgrad(dy, w, dx, rows, cin, cout, s, kind=EPI_NONE, aux=None):
     lib.linear_dgrad_fused(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, d, e, s)
 
 
-def _linear_wgrad(dy, x, w, bias, rows, cin, cout, need_w, need_b):
-    """(dw, dbias) of y = x w^T + bias on the weight-gradient side stream (ops._wgrad)."""
+def _linear_wgrad(dy, x, w, bias, rows, cin, cout, need_w, need_b, lddy=None):
+    """(dw, dbias) of y = x w^T + bias on the weight-gradient side stream (ops._wgrad); lddy: row stride of dy when it
+    is a column block of a wider buffer."""
+    lddy = cout if lddy is None else lddy
     if not need_w:
         db = None
         if need_b:
             db = grad_like(bias)
             part = scratch(lib.bn_bwd_parts(rows) * cout, dy.device)
-            lib.colsum(dy.data_ptr(), cout, rows, cout, part.data_ptr(), db.data_ptr(), _stream())
+            lib.colsum(dy.data_ptr(), lddy, rows, cout, part.data_ptr(), db.data_ptr(), _stream())
         return None, db
-    d = ConvDesc(rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, cin, cout)
+    d = ConvDesc(rows, 1, 1, cin, 1, 1, cout, 1, 1, 1, 0, cin, lddy)
     if bias is not None and need_b:
-        return ops._wgrad(dy, cout, x, cin, w, d, overlap=ops.OVERLAP_WGRAD, want_bias=True, bias=bias)
-    return ops._wgrad(dy, cout, x, cin, w, d, overlap=ops.OVERLAP_WGRAD), None
+        return ops._wgrad(dy, lddy, x, cin, w, d, overlap=ops.OVERLAP_WGRAD, want_bias=True, bias=bias)
+    return ops._wgrad(dy, lddy, x, cin, w, d, overlap=ops.OVERLAP_WGRAD), None
+
+
+def _back_to_back(a, b, c):
+    """Three equally shaped contiguous tensors that lie one after the other in memory (pack_qkv)."""
+    n = a.numel() * a.element_size()
+    return (a.shape == b.shape == c.shape and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + n and c.data_ptr() == b.data_ptr() + n)
+
+
+def pack_qkv(model):
+    """Re-seat que_proj / key_proj / val_proj of every SelfAttention (models/common.py:1167-1169 of the reference) on one
+    (3d, d) weight and one (3d,) bias buffer: same Parameters, same state_dict keys, same values, but the three projections
+    now run as ONE GEMM forward and ONE input-gradient GEMM (_TransformerBlock checks the addresses on every call, so a
+    model whose parameters were moved afterwards, e.g. by .to(), silently takes the three-GEMM path again).
+    Call before anything caches parameter addresses (optimizer pointer tables, gradient buckets).  Returns the count."""
+    n = 0
+    for m in model.modules():
+        if not all(hasattr(m, a) for a in ('que_proj', 'key_proj', 'val_proj')):
+            continue
+        lin = (m.que_proj, m.key_proj, m.val_proj)
+        if lin[0].bias is None or any(l.weight.shape != lin[0].weight.shape or l.weight.grad is not None for l in lin):
+            continue
+        for name in ('weight', 'bias'):
+            ps = [getattr(l, name) for l in lin]
+            if _back_to_back(*ps):
+                continue
+            flat = torch.cat([p.data.reshape(-1) for p in ps])
+            k = ps[0].numel()
+            for i, p in enumerate(ps):
+                p.data = flat[i * k:(i + 1) * k].view(ps[0].shape)
+        n += 1
+    return n
 
 
 def _ln_param_grads(x, stats, dy, gamma, beta, rows, c):
@@ -283,12 +317,18 @@ class _TransformerBlock(Function):
         new = lambda *shape: torch.empty(shape, dtype=x.dtype, device=dev)  # noqa: E731
         ln1y, st1 = torch.empty_like(x), new(rows, 2)
         lib.layernorm_fwd(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), ln1y.data_ptr(), st1.data_ptr(), rows, d, eps[0], s)
-        q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        for w, b, out in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):
-            _linear_fwd(ln1y, w, b, out, rows, d, d, s)
+        packed = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)      # pack_qkv(): one projection GEMM
+        if packed:
+            qkv = new(bsz, t, 3 * d)
+            _linear_fwd(ln1y, wq, bq, qkv, rows, d, 3 * d, s)
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        else:
+            q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            for w, b, out in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):
+                _linear_fwd(ln1y, w, b, out, rows, d, d, s)
         o, probs = torch.empty_like(x), new(bsz, heads, t, t)
-        lib.attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), probs.data_ptr(), bsz, heads, d // heads, d,
-                          ps[0], seeds[0], sd if ps[0] > 0 else None, s)
+        lib.attention_fwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), probs.data_ptr(), bsz, heads,
+                                  d // heads, 3 * d if packed else d, d, ps[0], seeds[0], sd if ps[0] > 0 else None, s)
         x1 = torch.empty_like(x)
         _linear_fwd(o, wo, bo, x1, rows, d, d, s, EPI_DROPOUT_RESIDUAL, aux=x, p=ps[1], seed=seeds[1],
                     seed_dev=sd if ps[1] > 0 else None)
@@ -300,14 +340,14 @@ class _TransformerBlock(Function):
         _linear_fwd(g, w2, c2, x2, rows, hid, d, s, EPI_DROPOUT_RESIDUAL, aux=x1, p=ps[2], seed=seeds[2],
                     seed_dev=sd if ps[2] > 0 else None)
         ctx.save_for_backward(x, st1, ln1y, q, k, v, probs, o, x1, st2, ln2y, h, g, *params)
-        ctx.cfg = (heads, ps, seeds)
+        ctx.cfg = (heads, ps, seeds, packed)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         x, st1, ln1y, q, k, v, probs, o, x1, st2, ln2y, h, g = ctx.saved_tensors[:13]
         g1, b1, wq, bq, wk, bk, wv, bv, wo, bo, g2, b2, w1, c1, w2, c2 = ctx.saved_tensors[13:]
-        heads, ps, seeds = ctx.cfg
+        heads, ps, seeds, packed = ctx.cfg
         need = ctx.needs_input_grad[5:]
         dx2 = dx2.contiguous()
         bsz, t, d = x.shape
@@ -315,8 +355,8 @@ class _TransformerBlock(Function):
         sd = seed_state(dev).data_ptr() if max(ps) > 0 else None
         grads = [None] * 16
 
-        def wgrad(dy, inp, w, b, iw, cin, cout):
-            grads[iw], grads[iw + 1] = _linear_wgrad(dy, inp, w, b, rows, cin, cout, need[iw], need[iw + 1])
+        def wgrad(dy, inp, w, b, iw, cin, cout, lddy=None):
+            grads[iw], grads[iw + 1] = _linear_wgrad(dy, inp, w, b, rows, cin, cout, need[iw], need[iw + 1], lddy)
 
         # ---- x2 = x1 + drop(mlp2(GELU(mlp0(ln_output(x1))))) ----
         if ps[2] > 0:
@@ -344,14 +384,22 @@ class _TransformerBlock(Function):
         wgrad(dy1, o, wo, bo, 8, d, d)
         do = torch.empty_like(x)
         _linear_dgrad(dy1, wo, do, rows, d, d, s)
-        dq, dk_, dv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
-                          dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, d, ps[0], seeds[0],
-                          sd if ps[0] > 0 else None, s)
+        ldq = 3 * d if packed else d
+        if packed:
+            dqkv = torch.empty((bsz, t, 3 * d), dtype=x.dtype, device=dev)
+            dq, dk_, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+        else:
+            dq, dk_, dv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        lib.attention_bwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
+                                  dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, ldq, d, ps[0], seeds[0],
+                                  sd if ps[0] > 0 else None, s)
         dln1 = torch.empty_like(x)
         for i, (dy, w, b) in enumerate(((dq, wq, bq), (dk_, wk, bk), (dv, wv, bv))):
-            wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d)
-            _linear_dgrad(dy, w, dln1, rows, d, d, s, EPI_ACCUMULATE if i else EPI_NONE, aux=dln1 if i else None)
+            wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d, ldq)
+            if not packed:
+                _linear_dgrad(dy, w, dln1, rows, d, d, s, EPI_ACCUMULATE if i else EPI_NONE, aux=dln1 if i else None)
+        if packed:
+            _linear_dgrad(dqkv, wq, dln1, rows, d, 3 * d, s)
         if need[0] or need[1]:
             grads[0], grads[1] = _ln_param_grads(x, st1, dln1, g1, b1, rows, d)
         dx = torch.empty_like(x)

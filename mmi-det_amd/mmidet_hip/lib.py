@@ -88,6 +88,9 @@ _SIGS = {
     'mmi_layernorm_bwd_params': (c_int, [P, P, P, P, P, P, c_int, c_int, P]),
     'mmi_attention_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
     'mmi_attention_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
+    'mmi_attention_fwd_strided': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, P, P]),
+    'mmi_attention_bwd_strided': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, P,
+                                          P]),
     'mmi_avgpool8_fwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
     'mmi_avgpool8_bwd': (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample_add_fwd': (c_int, [P, c_int, P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),

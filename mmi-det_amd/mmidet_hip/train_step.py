@@ -76,6 +76,8 @@ class TrainStep:
         self.reducer = reducer
         hyp = scale_hyp(HYP_SCRATCH if hyp is None else hyp, nc, imgsz)
         model.nc, model.hyp, model.gr = nc, hyp, 1.0                                    # train.py:693-695
+        if reducer is None:            # (a reducer has already keyed its gradient slots on the parameter addresses)
+            F2.pack_qkv(model)         # q/k/v projections of the fusion transformers as one GEMM each way
         self.ema = ModelEMA(model) if ema else None
         self.fused = fused_optimizer
         self.optimizer, self.accumulate = build_optimizer(model, hyp, batch_size * world_size, fused=fused_optimizer,

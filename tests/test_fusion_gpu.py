@@ -223,11 +223,14 @@ def _block_params(blk):
             blk.ln_output.weight, blk.ln_output.bias, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias)
 
 
+@pytest.mark.parametrize('packed', [False, True], ids=['three_projections', 'packed_qkv'])
 @pytest.mark.parametrize('B,C', [(2, 128), (16, 256), (3, 512), (16, 1024), (1, 160)])
-def test_transformer_block_matches_oracle(B, C):
+def test_transformer_block_matches_oracle(B, C, packed):
     """myTransformerBlock (models/common.py:1237-1267) as one fused autograd node against the oracle's module: output,
-    input gradient and the 16 parameter gradients.  (16, 256) and (16, 1024) are bench shapes (stream-K schedules)."""
+    input gradient and the 16 parameter gradients.  (16, 256) and (16, 1024) are bench shapes (stream-K schedules).
+    packed: after fusion_ops.pack_qkv the q/k/v projections run as one GEMM forward and one input-gradient GEMM."""
     import models.common as mc
+    from mmidet_hip import fusion_ops as F2
     from oracle import ref_model as R
     torch.manual_seed(C + B)
     ref = R.myTransformerBlock(C, C, C, 8, 4, 0.0, 0.0)
@@ -242,6 +245,9 @@ def test_transformer_block_matches_oracle(B, C):
     blk = mc.myTransformerBlock(C, C, C, 8, 4, 0.0, 0.0)
     blk.load_state_dict(ref.state_dict())
     blk.to(d).train()
+    if packed:
+        assert F2.pack_qkv(blk) == 1 and F2._back_to_back(blk.sa.que_proj.weight, blk.sa.key_proj.weight, blk.sa.val_proj.weight)
+        assert all(torch.equal(v.cpu(), ref.state_dict()[k]) for k, v in blk.state_dict().items())
     xg = x.to(d).requires_grad_()
     yg = blk(xg)
     yg.backward(go.to(d))

@@ -97,3 +97,34 @@ def test_highpass_mask_matches_reference_slicing():
     from mmidet_hip.fusion_ops import highpass_keep_mask
     mask = highpass_keep_mask()
     assert mask == (1 << 64) - 1 - (1 << (3 * 8 + 3))       # everything but unshifted bin (3,3)  
+
+
+def test_pack_qkv_keeps_parameters_and_state_dict():
+    """fusion_ops.pack_qkv re-seats que/key/val_proj on one buffer: same Parameter objects, keys and values; survives
+    load_state_dict; a deep copy (ModelEMA) or .to() simply ends up unpacked again."""
+    import copy
+
+    import models.common as mc
+    from mmidet_hip import fusion_ops as F2
+    torch.manual_seed(3)
+    gpt = mc.GPT(64, h=8, n_layer=2)
+    before = {k: v.clone() for k, v in gpt.state_dict().items()}
+    ids = [id(p) for p in gpt.parameters()]
+    assert F2.pack_qkv(gpt) == 2
+    assert ids == [id(p) for p in gpt.parameters()]
+    after = gpt.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    sa = gpt.trans_blocks[0].sa
+    assert F2._back_to_back(sa.que_proj.weight, sa.key_proj.weight, sa.val_proj.weight)
+    assert F2._back_to_back(sa.que_proj.bias, sa.key_proj.bias, sa.val_proj.bias)
+    assert F2.pack_qkv(gpt) == 2                                           # idempotent
+    other = mc.GPT(64, h=8, n_layer=2)
+    gpt.load_state_dict(other.state_dict())                                # in-place copies keep the packing
+    assert F2._back_to_back(sa.que_proj.weight, sa.key_proj.weight, sa.val_proj.weight)
+    assert torch.equal(sa.key_proj.weight, other.trans_blocks[0].sa.key_proj.weight)
+    clone = copy.deepcopy(gpt)
+    assert torch.equal(clone.trans_blocks[0].sa.val_proj.weight, sa.val_proj.weight)
+    sa.key_proj.weight.data.add_(1.0)                                      # a write through one view touches only that third
+    assert not torch.equal(sa.key_proj.weight, other.trans_blocks[0].sa.key_proj.weight)
+    assert torch.equal(sa.que_proj.weight, other.trans_blocks[0].sa.que_proj.weight)
+    assert torch.equal(sa.val_proj.weight, other.trans_blocks[0].sa.val_proj.weight)
