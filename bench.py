@@ -230,8 +230,8 @@ def main():
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x9', 'bf16x6', 'bf16x3'],
                     help='arithmetic of the conv/linear GEMMs in the TIMED region.  fp32 (default, the headline): exact fp32 '
                          'products on v_mfma_f32_32x32x2_f32.  bf16x6: every operand split into three bf16 terms, six bf16 MFMA '
-                         'products of total order <= 2, fp32 accumulation (GEMM 3e-7..1e-6 vs the fp32 kernels; full-depth '
-                         'gradients 4x less accurate than fp32).  bf16x9: all nine products (exact products; gradients as fp32). '
+                         'products of total order <= 2, fp32 accumulation (GEMM 3e-7..1e-6 vs the fp32 kernels).  bf16x9: all nine '
+                         'products (each product exact).  Both: full-depth gradients as the fp32 path over four seeds. '
                          'bf16x3: two terms, three products (GEMM 4.5e-6, full-depth gradients ~1e-2)')
     ap.add_argument('--no-split-probe', action='store_true', help='skip the extra split-bf16 measurement after the timed region')
     ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
@@ -432,9 +432,10 @@ def main():
         if split:
             what = {'bf16x9': 'three bf16 terms per operand (an exact representation of the fp32 significand), all nine products on '
                               'v_mfma_f32_32x32x16_bf16, fp32 accumulation: every product exact as with the fp32 MFMA; whole-step '
-                              'gradients vs the oracle as the fp32 path (median 9e-4, worst 3e-3 at full depth)',
+                              'gradients vs the oracle as the fp32 path (medians 9e-4..1.6e-3 over four seeds at full depth)',
                     'bf16x6': 'the six products of total order <= 2 (dropped terms <= 2^-24): a GEMM differs from the fp32 kernel by '
-                              '3e-7..1e-6, but full-depth gradients are 4x less accurate than fp32 (median 4e-3, worst 2e-2)',
+                              '3e-7..1e-6; full-depth gradients statistically as the fp32 path (four seeds: '
+                              'profiles/r01_gemm_modes_full_size_gradients.txt)',
                     'bf16x3': 'two bf16 terms, three products: a GEMM is off by 4.5e-6, predictions 1e-4, full-depth gradients ~1e-2'}
             out['gemm_modes_optional'] = {
                 'note': 'NOT the headline (which uses exact fp32 MFMA products): the same step with mmi_set_gemm_precision(3 / 2 / 1); '

@@ -88,8 +88,10 @@ int mmi_set_streamk_slots(int slots);
 /* Arithmetic of the conv / linear GEMMs (forward, dgrad, wgrad).  0 (default): exact fp32 products on
  * v_mfma_f32_32x32x2_f32.  Opt-in split forms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, each fp32 operand split
  * into bf16 terms when its tile is staged into LDS: 1 = two terms, three products (relative product error <= 2^-16);
- * 2 = three terms, the six products of total order <= 2 (dropped terms <= 2^-24 per product; one GEMM is at fp32 level, full-depth gradients are 4x worse than fp32's); 3 = three terms, all
- * nine products (each fp32 product exact).  A process-wide switch; takes effect at the next launch. */
+ * 2 = three terms, the six products of total order <= 2 (dropped terms <= 2^-24 per product); 3 = three terms, all
+ * nine products (each fp32 product exact).  Modes 2 and 3 are indistinguishable from mode 0 on a single GEMM (3e-7..1e-6) and on
+ * full-depth training gradients (profiles/r01_gemm_modes_full_size_gradients.txt); mode 1 is not (gradients 1e-2).
+ * A process-wide switch; takes effect at the next launch. */
 int mmi_set_gemm_precision(int mode);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */

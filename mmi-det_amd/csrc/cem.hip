@@ -253,18 +253,24 @@ __global__ void sobel_add_fwd_kernel(const float* __restrict__ r, int ldr, const
 }
 
 // backward pass 1: D[pix][k] = sum_{o%8==k} factor[o]*dt[pix][o]; partial sums of dbias[o] = sum dt_o and
-// dfactor[o] = sum dt_o * stencil_{o%8}(R): partials[block][2][C]
+// dfactor[o] = sum dt_o * stencil_{o%8}(R): partials[block][2][C].  A thread walks SOBEL_PPT pixels (256 apart, so a wave
+// still reads consecutive pixels) before the 48 wave reductions, which would otherwise cost more than the HBM traffic.
+constexpr int SOBEL_PPT = 8;
 template <int C>
 __global__ __launch_bounds__(256) void sobel_bwd1_kernel(const float* __restrict__ dt, int ldd, const float* __restrict__ R,
                                                          const float* __restrict__ factor, float* __restrict__ D,
                                                          float* __restrict__ partials, int N, int H, int W) {
   __shared__ float red[2][4][C];
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < (int64_t)N * H * W;
-  float db[C], df[C];
+  const int64_t npix = (int64_t)N * H * W;
+  float db[C], df[C], fac[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) db[c] = df[c] = 0.f;
-  if (live) {
+  for (int c = 0; c < C; ++c) {
+    db[c] = df[c] = 0.f;
+    fac[c] = factor[c];
+  }
+  for (int it = 0; it < SOBEL_PPT; ++it) {
+    const int64_t p = ((int64_t)blockIdx.x * SOBEL_PPT + it) * 256 + threadIdx.x;
+    if (p >= npix) break;
     const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
     float nb[9], s[8], dk[8];
     load9(R, n, h, w, H, W, nb);
@@ -277,9 +283,9 @@ __global__ __launch_bounds__(256) void sobel_bwd1_kernel(const float* __restrict
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        db[c + k] = v[k];
-        df[c + k] = v[k] * s[(c + k) & 7];
-        dk[(c + k) & 7] += factor[c + k] * v[k];
+        db[c + k] += v[k];
+        df[c + k] += v[k] * s[(c + k) & 7];
+        dk[(c + k) & 7] += fac[c + k] * v[k];
       }
     }
     f32x4 d0 = {dk[0], dk[1], dk[2], dk[3]}, d1 = {dk[4], dk[5], dk[6], dk[7]};
@@ -418,12 +424,12 @@ extern "C" int mmi_sobel_add_bwd(const float* dt, int ldd, const float* chansum,
   MMI_CHECK_ARG(C == 24 && ldd % 4 == 0 && lddr % 4 == 0, "mmi_sobel_add_bwd: the stencil bank is the 24-channel CEM one");
   hipStream_t s = (hipStream_t)stream;
   const int64_t npix = (int64_t)N * H * W;
-  const int blocks = cdiv(npix, 256);
+  const int blocks = cdiv(npix, 256), blocks1 = cdiv(npix, 256 * SOBEL_PPT);
   float* D = (float*)workspace;
   float* part = D + npix * 8;
-  hipLaunchKernelGGL(sobel_bwd1_kernel<24>, dim3(blocks), dim3(256), 0, s, dt, ldd, chansum, factor, D, part, N, H, W);
+  hipLaunchKernelGGL(sobel_bwd1_kernel<24>, dim3(blocks1), dim3(256), 0, s, dt, ldd, chansum, factor, D, part, N, H, W);
   MMI_CHECK_LAUNCH("mmi_sobel_add_bwd(1)");
   hipLaunchKernelGGL(sobel_bwd2_kernel<24>, dim3(blocks), dim3(256), 0, s, dt, ldd, (const float*)D, dr, lddr, N, H, W);
   MMI_CHECK_LAUNCH("mmi_sobel_add_bwd(2)");
-  return mmi_pair_colsum(part, blocks, C, dbias, dfactor, stream);  // partials[block][2][C] -> dbias (slot 0), dfactor (slot 1)
+  return mmi_pair_colsum(part, blocks1, C, dbias, dfactor, stream);  // partials[block][2][C] -> dbias (slot 0), dfactor (slot 1)
 }

@@ -219,7 +219,7 @@ struct SkRange {
 // is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 instructions of 8 passes per 16 k instead
 // of 8 instructions of 16 passes, relative error of a product <= 2^-16 (the dropped lo*lo term is 2^-18).
 // PREC = 2: three bf16 terms per operand (x = t0 + t1 + t2, residual <= 2^-25 |x|) and the six products of total order <= 2
-// (t0*t0, t0*t1, t1*t0, t0*t2, t2*t0, t1*t1): dropped terms <= 2^-24 per product (fp32 level for one GEMM, not for a deep net's gradients) at 6 x 8 passes per 16 k.
+// (t0*t0, t0*t1, t1*t0, t0*t2, t2*t0, t1*t1): dropped terms <= 2^-24 per product, at 6 x 8 passes per 16 k.
 // PREC = 3: the same three terms -- which represent a 24-bit significand exactly -- and all nine products, each exact in
 // fp32: every fp32 product is formed exactly, as by the fp32 MFMA; only the order of the fp32 accumulation differs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -1,6 +1,6 @@
 """GPU parity of the OPT-IN split-bf16 GEMM arithmetics (mmi_set_gemm_precision, csrc/igemm.hip PREC): mode 1 = two bf16
 terms per operand, three products (hi*hi + hi*lo + lo*hi); mode 2 = three terms, the six products of total order <= 2
-(fp32-level for one GEMM and on these shallow graphs; at full depth only mode 3 is, see test_model_gpu.py); mode 3 = three terms, all nine products (every fp32 product exact); all on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same checks and
+(fp32-level accuracy, also at full depth: test_model_gpu.py); mode 3 = three terms, all nine products (every fp32 product exact); all on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same checks and
 the same tolerances as the default fp32-MFMA path for every op and for the model's forward and loss; the whole-step
 parameter gradients get the looser bound they need (see test_train_step_split_bf16_matches_oracle)."""
 import pytest
