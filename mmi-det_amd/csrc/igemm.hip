@@ -675,10 +675,13 @@ struct WgradP {
 
 // LDS stages of the wgrad kernel: single-buffered (3+ workgroups per CU, +3..10 % measured on the 3x3 layers) except for
 // the 64x64 tile of the tall-skinny 1x1 layers, whose short MFMA phase cannot hide a second barrier per slab.
+#ifndef MMI_WGRAD_OCC
+#define MMI_WGRAD_OCC 3
+#endif
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
 
 template <int BM, int BN, bool VEC, int PREC = 0>
-__global__ __launch_bounds__(256, (BK == 32 && PREC < 2) ? 3 : 2) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && PREC < 2) ? 3 : 2)) void wgrad_kernel(WgradP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);
   constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;

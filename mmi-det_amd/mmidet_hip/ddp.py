@@ -38,6 +38,7 @@ class GradReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         params = [p for p in params if p.requires_grad]
+        bucket_mb = float(__import__('os').environ.get('MMIDET_BUCKET_MB', bucket_mb))   # (tuning override)
         cap = int(bucket_mb * 1024 * 1024) // 4
         self.buckets, cur, n = [], [], 0
         for p in reversed(params):
