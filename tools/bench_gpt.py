@@ -11,7 +11,7 @@ import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, os.path.join(R, 'mmi-det_amd')]
 import bench  # noqa: E402
-from mmidet_hip import ops  # noqa: E402
+from mmidet_hip import fusion_ops as F2, ops  # noqa: E402
 from models.common import GPT  # noqa: E402
 from models.yolo_test import Model  # noqa: E402
 
@@ -20,6 +20,8 @@ GRAPH = len(sys.argv) > 2 and sys.argv[2] == 'graph'
 cfg = bench.load_cfg('l_fourier')
 dev = torch.device('cuda:0')
 model = Model(cfg).to(dev).train()
+if os.environ.get('BENCH_GPT_PACK', '1') != '0':
+    F2.pack_qkv(model)              # what TrainStep does: q/k/v projections as one GEMM
 for m in model.modules():
     if isinstance(m, torch.nn.Dropout):
         m.p = 0.1
