@@ -93,6 +93,10 @@ int mmi_set_streamk_slots(int slots);
  * full-depth training gradients (profiles/r01_gemm_modes_full_size_gradients.txt); mode 1 is not (gradients 1e-2).
  * A process-wide switch; takes effect at the next launch. */
 int mmi_set_gemm_precision(int mode);
+/* A/B switch of the forward/dgrad tile loaders: 1 (default) = uniform-tap buffer-load loaders wherever the channel count is a
+ * multiple of 32 and the tensors are below 2 GiB (same arithmetic, same results bit for bit; ~10 instead of ~100 address
+ * instructions per K slab), 0 = the general cursor-based loaders everywhere.  Returns the old value. */
+int mmi_set_uniform_loaders(int on);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
 int mmi_set_tile_override(int bm, int bn);

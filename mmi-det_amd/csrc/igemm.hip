@@ -74,6 +74,8 @@ struct IgemmP {
   const uint64_t* seed_dev;
   uint32_t drop_thresh;
   float inv_keep;
+  // uniform-tap loaders: byte extents of the A tensor (incl. the margin in front of it) and of the weights
+  uint32_t a_bytes, b_bytes;
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -252,9 +254,17 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 
 // EPI: the token-side Linear epilogues (p.epi) are compiled in; a separate instantiation, because their registers
 // (64-bit hash, erf) would otherwise cost the convolution kernels occupancy.
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false>
+// UNI (uniform-tap loaders): when the channel count is a multiple of the slab depth, every thread of the workgroup is in
+// the same filter tap during a slab, so the tap's pixel displacement and the channel offset are one SCALAR; a thread's part
+// of an address (its rows, its k lane) is computed once per tile, tap validity is one bit per (row, tap), and the loads are
+// buffer loads (SGPR resource + per-lane offset + scalar offset) whose out-of-range lanes return zero.  That leaves about
+// 10 VALU instructions per K slab instead of 90-160: tools/mfma_mix.hip shows that VALU instructions issued next to an MFMA
+// stream cost MFMA throughput at three waves per SIMD (1 per MFMA: 87 % of peak, 2: 80 %, LDS reads: nothing), which is
+// exactly where the cursor-based loaders (1.4-2.9 VALU per MFMA, a third of them 64-bit) had left these kernels.
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? 3 : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
+  static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
   constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
   constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;                // highest total order of the products kept
   // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (36 or 52 floats: both make
@@ -294,6 +304,12 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
   const int kq = (t % KT) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
   const int lrow = t / KT;      // 0..RPP-1
   const int l31 = lane & 31, lh = lane >> 5;
+  __amdgpu_buffer_rsrc_t srd_a, srd_b;
+  if constexpr (UNI) {
+    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;  // floats in front of A that row offsets may reach into
+    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - margin), 0, (int)p.a_bytes, 0x00020000);
+    srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  }
 
   // iteration range of this workgroup: data-parallel = the nk slabs of one tile; stream-K = an even share of everything
   SkRange sk{0, 0};
@@ -358,12 +374,64 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
     constexpr int NB = DGRAD ? KB_IT : RB;
     f32x4 rb[NB];
 
+    // ---- UNI: per-thread address parts and tap-validity bits of this tile (see the kernel's header comment) ----
+    // Source position of row r under tap (ti, tj):  ih = ihb[r] + sgn * dh * ti,  iw = iwb[r] + sgn * dw * tj  with
+    // forward: sgn = +1, (dh, dw) = (khs, kws), ihb = p*stride - pad + kh0;   dgrad (stride 1, or one parity class of a
+    // stride-2 layer): sgn = -1, ihb = (p + pad - kh0) >> sh, (dh, dw) = (khs, kws) >> sh.  Offsets are taken from the lowest
+    // position any tap reaches, shifted by a margin of KH rows + KW pixels so that they are never negative.
+    constexpr uint32_t OOB = 0x80000000u;  // >= num_records (host checks that every tensor is below 2 GiB)
+    uint32_t aoff[UNI ? RA : 1], amask[UNI ? RA : 1], boff[UNI ? NB : 1];
+    const int u_sh = (DGRAD && p.stride == 2) ? 1 : 0;
+    const int u_dh = tp.khs >> u_sh, u_dw = tp.kws >> u_sh;
+    const int u_nth = ntaps / tp.ntw;
+    if constexpr (UNI) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        aoff[i] = OOB;
+        amask[i] = 0xFFFFFFFFu;
+        if (rows[i].base >= 0) {
+          const int ihb = DGRAD ? ((rows[i].ph - tp.kh0) >> u_sh) : rows[i].ph + tp.kh0;
+          const int iwb = DGRAD ? ((rows[i].qw - tp.kw0) >> u_sh) : rows[i].qw + tp.kw0;
+          const int ihlo = DGRAD ? ihb - u_dh * (u_nth - 1) : ihb, iwlo = DGRAD ? iwb - u_dw * (tp.ntw - 1) : iwb;
+          const int64_t pix = rows[i].base + (int64_t)(ihlo + p.KH) * p.Ws + iwlo + p.KW;
+          aoff[i] = (uint32_t)((pix * p.lda + kq) * 4);
+          uint32_t bad = 0;
+          for (int ti = 0; ti < u_nth; ++ti) {
+            const int ih = DGRAD ? ihb - u_dh * ti : ihb + u_dh * ti;
+            for (int tj = 0; tj < tp.ntw; ++tj) {
+              const int iw = DGRAD ? iwb - u_dw * tj : iwb + u_dw * tj;
+              if (ih < 0 || iw < 0 || ih >= p.Hs || iw >= p.Ws) bad |= 1u << (ti * tp.ntw + tj);
+            }
+          }
+          amask[i] = bad;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (!DGRAD) {
+          const int n = n0 + lrow + RPP * i;
+          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)n * p.ldb + kq) * 4) : OOB;
+        } else {
+          const int n = n0 + (t % VPR) * 4;
+          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)(t / VPR + RPI * i) * p.ldb + n) * 4) : OOB;
+        }
+      }
+    }
+    // the slab's scalars: channel offset inside the tap, tap coordinates (clamped to the last slab: see advance())
+    int u_c0 = 0, u_ti = 0, u_tj = 0;
+
     // Vector path: division-free K cursors (advanced by one slab per step) and branch-free loads (an invalid lane reads
     // the zero source), so the loads of the NEXT slab can be issued piecewise between the MFMA groups of the current one
     // and their address arithmetic runs in the MFMA shadow.
     KCur ca, cb[NB];
     int k0cur = ks0 * BK;
-    if (VEC) {
+    if constexpr (UNI) {
+      const int tap0 = k0cur / p.Kc;
+      u_c0 = k0cur - tap0 * p.Kc;
+      u_ti = tap0 / tp.ntw;
+      u_tj = tap0 - u_ti * tp.ntw;
+    }
+    if (VEC && !UNI) {
       ca.init(k0cur + kq, p.Kc, tp.ntw);
       if (DGRAD) {
 #pragma unroll
@@ -373,6 +441,14 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
     auto load_a_row = [&](int i) {
       if (!VEC) {
         ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
+        return;
+      }
+      if constexpr (UNI) {
+        const int tap = u_ti * tp.ntw + u_tj;
+        const int dpix = DGRAD ? (u_nth - 1 - u_ti) * u_dh * p.Ws + (tp.ntw - 1 - u_tj) * u_dw : u_ti * u_dh * p.Ws + u_tj * u_dw;
+        const uint32_t soff = (uint32_t)(dpix * p.lda + u_c0) * 4u;
+        const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe(amask[i], tap, 1);   // -1 where this tap leaves the image
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
         return;
       }
       int64_t pix = 0;
@@ -385,12 +461,22 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
           rb[i] = load_b_nk<VEC>(p, n0 + lrow + RPP * i, k0cur + kq);
           return;
         }
+        if constexpr (UNI) {
+          const int tapw = (tp.kh0 + tp.khs * u_ti) * p.KW + tp.kw0 + tp.kws * u_tj;   // (forward: all taps, so tapw = tap)
+          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(tapw * p.Kc + u_c0) * 4u, 0));
+          return;
+        }
         const int n = n0 + lrow + RPP * i, k = k0cur + kq;
         const bool ok = (n < p.Ncol) & (k < tp.Ktot);
         rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
       } else {
         if (!VEC) {
           rb[i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+          return;
+        }
+        if constexpr (UNI) {
+          const int tapw = (tp.kh0 + tp.khs * u_ti) * p.KW + tp.kw0 + tp.kws * u_tj;
+          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * 4u, 0));
           return;
         }
         const int n = n0 + (t % VPR) * 4;
@@ -401,7 +487,21 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
     };
     auto advance = [&]() {  // move every cursor to the next slab
       k0cur += BK;
-      if (VEC) {
+      if constexpr (UNI) {
+        // Past the last slab the cursor stays where it is: the surplus prefetch of the last iteration then re-reads the last
+        // slab (a scalar offset beyond the tap table would leave the buffer's range check, which covers the lane offset).
+        if (k0cur < tp.Ktot) {
+          u_c0 += BK;
+          if (u_c0 >= p.Kc) {
+            u_c0 = 0;
+            if (++u_tj == tp.ntw) {
+              u_tj = 0;
+              ++u_ti;
+            }
+          }
+        }
+      }
+      if (VEC && !UNI) {
         ca.advance(p.Kc, tp.ntw);
         if (DGRAD) {
 #pragma unroll
@@ -976,6 +1076,7 @@ struct FwdPlan {
   int bm, bn, mtiles, ntiles;
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
+int g_uniform_loaders = 1;  // mmi_set_uniform_loaders (A/B switch): 1 = use the uniform-tap loaders where they apply
 int g_gemm_prec = 0;  // mmi_set_gemm_precision: 0 = exact fp32 MFMA, 1 = split-bf16 products for forward-layout GEMMs
 int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
 FwdPlan plan_tiles(int64_t M, int Ncol) {
@@ -1086,6 +1187,19 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   }
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
+  // uniform-tap loaders (igemm_kernel<..., UNI>): whole slabs inside one tap, tap table in 32 bits, 31-bit byte offsets
+  bool uni = false;
+  if (vec && g_uniform_loaders && g_gemm_prec == 0 && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
+    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;
+    const int64_t npix = (int64_t)(p.M / ((int64_t)p.P * p.Q)) * p.Hs * p.Ws;
+    const int64_t a_bytes = (margin + (npix - 1) * p.lda + p.Kc) * 4;
+    const int64_t b_bytes = DGRAD ? (int64_t)p.Kc * p.ldb * 4 : (int64_t)p.Ncol * p.ldb * 4;
+    if (a_bytes < (1LL << 31) && b_bytes < (1LL << 31)) {
+      uni = true;
+      p.a_bytes = (uint32_t)a_bytes;
+      p.b_bytes = (uint32_t)b_bytes;
+    }
+  }
   if (f.sk_grid > 0) {
     if (workspace == nullptr || workspace_bytes < sk_workspace_bytes(f) || ((uintptr_t)workspace & 15)) {
       mmi_set_error("%s: this shape runs the stream-K schedule and needs a 16-byte aligned workspace of %zu bytes (got %zu)",
@@ -1113,7 +1227,10 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
-    if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
+    if (uni) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
+    } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
     MMI_CHECK_LAUNCH(who);
     return MMI_OK;
@@ -1142,6 +1259,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     }
     if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
     else LAUNCH(64, 64, false);
+  } else if (uni) {
+#define LAUNCH_UNI(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 0, EPI, true>), grid, block, 0, s, p)
+    if (f.bm == 128 && f.bn == 128) LAUNCH_UNI(128, 128);
+    else if (f.bm == 128 && f.bn == 64) LAUNCH_UNI(128, 64);
+    else LAUNCH_UNI(64, 64);
+#undef LAUNCH_UNI
   } else if (f.bm == 128 && f.bn == 128) LAUNCH(128, 128, true);
   else if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, true);
   else LAUNCH(64, 64, true);
@@ -1183,6 +1306,12 @@ extern "C" int mmi_set_gemm_precision(int mode) {
   MMI_CHECK_ARG(mode >= 0 && mode <= 3, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9)", mode);
   g_gemm_prec = mode;
   return MMI_OK;
+}
+
+extern "C" int mmi_set_uniform_loaders(int on) {
+  const int old = g_uniform_loaders;
+  g_uniform_loaders = on ? 1 : 0;
+  return old;
 }
 
 extern "C" int mmi_set_tile_override(int bm, int bn) {

@@ -40,6 +40,7 @@ _SIGS = {
     'mmi_set_streamk_slots': (c_int, [c_int]),
     'mmi_set_tile_override': (c_int, [c_int, c_int]),
     'mmi_set_gemm_precision': (c_int, [c_int]),
+    'mmi_set_uniform_loaders': (c_int, [c_int]),
     'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_fwd': (c_int, [P, P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_bias_act_fwd': (c_int, [P, P, P, P, c_int, c_int, P, P, c_size_t, POINTER(ConvDesc), P]),
@@ -107,7 +108,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

