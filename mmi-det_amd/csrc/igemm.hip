@@ -771,6 +771,7 @@ struct WgradP {
   const float* zero;
   int Mpix, Cout, Cin, KH, KW, Ho, Wo, H, W, stride, pad, ldx, ldy, Ntot, chunk, mtiles, ntiles, splits;
   int64_t slab_stride;
+  uint32_t x_bytes;  // TAB loaders: byte extent of x including the margin in front of it
 };
 
 // LDS stages of the wgrad kernel: single-buffered (3+ workgroups per CU, +3..10 % measured on the 3x3 layers) except for
@@ -780,9 +781,16 @@ struct WgradP {
 #endif
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
 
-template <int BM, int BN, bool VEC, int PREC = 0>
+// TAB (pixel-table loaders, the wgrad counterpart of the uniform-tap loaders above).  Here K runs over output pixels, so
+// what every thread of a row has in common is the pixel: per slab ONE wave (taking turns) writes a 32-entry LDS table
+// {byte offset of the pixel's top-left source position, bit mask of the taps that leave the image (all ones past the
+// split's end)}; a loader thread adds its own constant tap/channel displacement, tests its own tap bit (2 VALU) and issues
+// a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
+// resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
+template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
 __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && PREC < 2) ? 3 : 2)) void wgrad_kernel(WgradP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
+  static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);
   constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -794,6 +802,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   constexpr int A_ELEMS = PREC >= 1 ? NP * BK * A_RSB / 4 : BK * BM, B_ELEMS = PREC >= 1 ? NP * BK * B_RSB / 4 : BK * BN;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   __shared__ __align__(16) float smem[MMI_WGRAD_STAGES * STAGE];
+  __shared__ uint2 ptab[TAB ? 2 : 1][TAB ? BK : 1];  // TAB: {source offset, invalid-tap mask} per pixel row, two slabs
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -849,8 +858,62 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     coh[i] = rem / p.Wo;
     cow[i] = rem - coh[i] * p.Wo;
   }
+  // ---- TAB state ----
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t a_voff[TAB ? ITA : 1], b_tapoff = 0;
+  int b_tapbit = 0, tab_sel = 0;
+  int timg = 0, toh = 0, tow = 0, tpix = 0;  // this wave's table cursor: pixel kbeg + (wave + 4 j) * BK + lane
+  __amdgpu_buffer_rsrc_t srd_x;
+  if constexpr (TAB) {
+#pragma unroll
+    for (int i = 0; i < ITA; ++i) a_voff[i] = am < p.Cout ? (uint32_t)(((akr + RPA * i) * p.ldy + am) * 4) : OOB;
+    b_tapbit = b_kh[0] * p.KW + b_kw[0];
+    b_tapoff = b_ok[0] ? (uint32_t)(((b_kh[0] * p.W + b_kw[0]) * p.ldx + b_ci[0]) * 4) : OOB;
+    const int64_t margin = ((int64_t)p.KH * p.W + p.KW) * p.ldx;
+    srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X - margin), 0, (int)p.x_bytes, 0x00020000);
+    tpix = kbeg + wave * BK + (lane & (BK - 1));
+    timg = tpix / howo;
+    const int rem = tpix - timg * howo;
+    toh = rem / p.Wo;
+    tow = rem - toh * p.Wo;
+  }
+  // wave (j & 3) writes the table of slab j (lanes 0..BK-1), then moves its cursor four slabs on
+  auto build_table = [&](int j) {
+    if constexpr (TAB) {
+      if (wave == (j & 3) && lane < BK) {
+        uint2 e = {0u, 0xFFFFFFFFu};
+        if (tpix < kend) {
+          const int ih0 = toh * p.stride - p.pad, iw0 = tow * p.stride - p.pad;
+          e.x = (uint32_t)(((((int64_t)timg * p.H + ih0 + p.KH) * p.W + iw0 + p.KW) * p.ldx) * 4);
+          uint32_t bw = 0, m = 0;
+          for (int kw = 0; kw < p.KW; ++kw) bw |= ((unsigned)(iw0 + kw) >= (unsigned)p.W ? 1u : 0u) << kw;
+          const uint32_t roww = (1u << p.KW) - 1u;
+          for (int kh = 0; kh < p.KH; ++kh) m |= (((unsigned)(ih0 + kh) >= (unsigned)p.H) ? roww : bw) << (kh * p.KW);
+          e.y = m;
+        }
+        ptab[j & 1][lane] = e;
+        tpix += 4 * BK;
+        if (howo == 1) {
+          timg += 4 * BK;
+        } else {
+          tow += 4 * BK;
+          while (tow >= p.Wo) {
+            tow -= p.Wo;
+            if (++toh == p.Ho) {
+              toh = 0;
+              ++timg;
+            }
+          }
+        }
+      }
+    }
+  };
   auto advance = [&]() {
     k0cur += BK;
+    if constexpr (TAB) {
+      tab_sel ^= 1;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < ITB; ++i) {
       if (howo == 1) {  // Linear layers: every row is its own 1x1 "image"
@@ -868,6 +931,14 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     }
   };
   auto load_a_row = [&](int i) {
+    if constexpr (TAB) {
+      // the resource starts at the slab's first dy row and ends with the split: rows past the end are out of range -> 0
+      const int64_t left = (int64_t)(kend - k0cur) * p.ldy * 4;
+      const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.DY + (int64_t)k0cur * p.ldy), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0, 0x00020000);
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, a_voff[i], 0, 0));
+      return;
+    }
     const int pix = k0cur + akr + RPA * i;
     if (VEC) {  // branch-free: an invalid lane reads the base address and is zeroed
       const bool ok = (pix < kend) & (am < p.Cout);
@@ -884,6 +955,12 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     }
   };
   auto load_b_row = [&](int i) {
+    if constexpr (TAB) {
+      const uint2 e = ptab[tab_sel][bkr + RPB * i];
+      const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe((int)e.y, b_tapbit, 1);  // -1: this thread's tap leaves the image
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
+      return;
+    }
     const int pix = k0cur + bkr + RPB * i;
     const int ih0 = coh[i] * p.stride - p.pad, iw0 = cow[i] * p.stride - p.pad;
     if (VEC) {
@@ -946,6 +1023,11 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
+  if constexpr (TAB) {
+    build_table(0);
+    build_table(1);
+    __syncthreads();
+  }
   if (nk > 0) {
     gload();
     lstore(0);
@@ -1015,6 +1097,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     __builtin_amdgcn_sched_barrier(0);
     if (MMI_WGRAD_STAGES == 1) __syncthreads();
     lstore(MMI_WGRAD_STAGES == 2 ? ((ks + 1) & 1) : 0);
+    build_table(ks + 2);  // read during the next iteration (its loads are those of slab ks + 2); shares a buffer with slab ks
     __syncthreads();
   }
 
@@ -1568,6 +1651,16 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = g.splits > 1 ? slab : 0;
   const dim3 grid(g.mtiles * g.ntiles, g.splits), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // pixel-table loaders (wgrad_kernel<..., TAB>): tap mask in 32 bits, 31-bit byte offsets into x
+  bool tab = false;
+  if (g.vec && g_uniform_loaders && g_gemm_prec == 0 && d->KH * d->KW <= 32) {
+    const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
+    const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4;
+    if (x_bytes < (1LL << 31)) {
+      tab = true;
+      p.x_bytes = (uint32_t)x_bytes;
+    }
+  }
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
   if (g.vec && g_gemm_prec >= 1) {
@@ -1583,7 +1676,14 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
     else LAUNCHW3(64, 64);
 #undef LAUNCHW3
   } else if (!g.vec) LAUNCHW(64, 64, false);
-  else if (g.bm == 128 && g.bn == 128) LAUNCHW(128, 128, true);
+  else if (tab) {
+#define LAUNCHWT(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 0, true>), grid, block, 0, s, p)
+    if (g.bm == 128 && g.bn == 128) LAUNCHWT(128, 128);
+    else if (g.bm == 128) LAUNCHWT(128, 64);
+    else if (g.bn == 128) LAUNCHWT(64, 128);
+    else LAUNCHWT(64, 64);
+#undef LAUNCHWT
+  } else if (g.bm == 128 && g.bn == 128) LAUNCHW(128, 128, true);
   else if (g.bm == 128) LAUNCHW(128, 64, true);
   else if (g.bn == 128) LAUNCHW(64, 128, true);
   else LAUNCHW(64, 64, true);
