@@ -261,8 +261,11 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // 10 VALU instructions per K slab instead of 90-160: tools/mfma_mix.hip shows that VALU instructions issued next to an MFMA
 // stream cost MFMA throughput at three waves per SIMD (1 per MFMA: 87 % of peak, 2: 80 %, LDS reads: nothing), which is
 // exactly where the cursor-based loaders (1.4-2.9 VALU per MFMA, a third of them 64-bit) had left these kernels.
+#ifndef MMI_UNI_OCC
+#define MMI_UNI_OCC 3
+#endif
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? 3 : 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
   constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
@@ -1211,7 +1214,12 @@ int sk_occupancy(int bn) {
     hipError_t e;
 #define OCC(P_) (bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, P_>, 256, 0) \
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, P_>, 256, 0))
-    e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : (g_gemm_prec == 2 ? OCC(2) : OCC(3)));
+    // (fp32: the uniform-tap variant is what nearly every stream-K shape runs; the few others fit its grid as well)
+    if (g_gemm_prec == 0 && g_uniform_loaders)
+      e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 0, false, true>, 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 0, false, true>, 256, 0);
+    else
+      e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : (g_gemm_prec == 2 ? OCC(2) : OCC(3)));
 #undef OCC
     c = (e == hipSuccess && n > 0) ? n : (g_gemm_prec >= 2 ? 2 : 3);
     (void)hipGetLastError();
