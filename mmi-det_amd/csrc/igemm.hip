@@ -74,8 +74,9 @@ struct IgemmP {
   const uint64_t* seed_dev;
   uint32_t drop_thresh;
   float inv_keep;
-  // uniform-tap loaders: byte extents of the A tensor (incl. the margin in front of it) and of the weights
-  uint32_t a_bytes, b_bytes;
+  // uniform-tap loaders: byte extents of the A tensor (incl. the margin in front of it) and of the weights; of the output
+  // (0: too large for 31-bit offsets, the epilogue keeps its pointer stores)
+  uint32_t a_bytes, b_bytes, c_bytes;
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -341,12 +342,17 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
+    // a 1x1 stride-1 layer (C3's cv1/cv2/cv3, every Linear): source pixel = output pixel, no taps to test, no divisions
+    const bool lin1 = UNI && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;  // uniform
     RowInfo rows[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + lrow + RPP * i;
       int orow = -1;
-      if (m < Mc) {
+      if (lin1) {
+        rows[i].base = m < Mc ? 0 : -1;
+        rows[i].ph = rows[i].qw = 0;
+      } else if (m < Mc) {
         const int pq = Pc * Qc;
         const int img = m / pq, rem = m - img * pq;
         int pp = rem / Qc, qq = rem - pp * Qc;
@@ -392,20 +398,24 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
       for (int i = 0; i < RA; ++i) {
         aoff[i] = OOB;
         amask[i] = 0xFFFFFFFFu;
-        if (rows[i].base >= 0) {
+        if (lin1) {
+          if (rows[i].base >= 0) {
+            aoff[i] = (uint32_t)((((int64_t)(m0 + lrow + RPP * i) + p.Ws + 1) * p.lda + kq) * 4);  // margin = KH*Ws + KW pixels
+            amask[i] = 0u;
+          }
+        } else if (rows[i].base >= 0) {
           const int ihb = DGRAD ? ((rows[i].ph - tp.kh0) >> u_sh) : rows[i].ph + tp.kh0;
           const int iwb = DGRAD ? ((rows[i].qw - tp.kw0) >> u_sh) : rows[i].qw + tp.kw0;
           const int ihlo = DGRAD ? ihb - u_dh * (u_nth - 1) : ihb, iwlo = DGRAD ? iwb - u_dw * (tp.ntw - 1) : iwb;
           const int64_t pix = rows[i].base + (int64_t)(ihlo + p.KH) * p.Ws + iwlo + p.KW;
           aoff[i] = (uint32_t)((pix * p.lda + kq) * 4);
-          uint32_t bad = 0;
-          for (int ti = 0; ti < u_nth; ++ti) {
-            const int ih = DGRAD ? ihb - u_dh * ti : ihb + u_dh * ti;
-            for (int tj = 0; tj < tp.ntw; ++tj) {
-              const int iw = DGRAD ? iwb - u_dw * tj : iwb + u_dw * tj;
-              if (ih < 0 || iw < 0 || ih >= p.Hs || iw >= p.Ws) bad |= 1u << (ti * tp.ntw + tj);
-            }
-          }
+          // separable: a tap is out if its row is out or its column is out
+          uint32_t bw = 0, bad = 0;
+          for (int tj = 0; tj < tp.ntw; ++tj)
+            bw |= ((unsigned)(DGRAD ? iwb - u_dw * tj : iwb + u_dw * tj) >= (unsigned)p.Ws ? 1u : 0u) << tj;
+          const uint32_t roww = (1u << tp.ntw) - 1u;
+          for (int ti = 0; ti < u_nth; ++ti)
+            bad |= ((unsigned)(DGRAD ? ihb - u_dh * ti : ihb + u_dh * ti) >= (unsigned)p.Hs ? roww : bw) << (ti * tp.ntw);
           amask[i] = bad;
         }
       }
@@ -707,12 +717,32 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
 
     // ---- epilogue: C/D layout of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const uint64_t epi_seed = EPI ? p.seed + (p.seed_dev != nullptr ? p.seed_dev[0] : 0ull) : 0ull;
+    // Interior tiles of the plain training epilogue (bias / BN statistics only): every store is a buffer store whose row
+    // displacement is a scalar, so an element costs its statistics (add, fma) and nothing else -- the epilogue runs beside
+    // other workgroups' MFMA streams, where VALU instructions are not free (1x1 layers: 4 K slabs per tile).
+    const bool fast_store = UNI && !EPI && !par && p.c_bytes != 0 && p.act == MMI_ACT_NONE && p.res == nullptr &&
+                            m0 + BM <= Mc && n0 + BN <= p.Ncol;  // uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WN + j * 32 + l31;
       const bool cok = col < p.Ncol;
       const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
       float s1 = 0.f, s2 = 0.f;
+      if (UNI && fast_store) {
+        const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
+        const uint32_t voff = (uint32_t)(((m0 + wm * WM + 4 * lh) * p.ldc + col) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r] + bv;
+            s1 += v;
+            s2 += v * v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_c, voff,
+                                                  (uint32_t)((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc) * 4u, 0);
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1289,6 +1319,8 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       uni = true;
       p.a_bytes = (uint32_t)a_bytes;
       p.b_bytes = (uint32_t)b_bytes;
+      const int64_t c_bytes = ((int64_t)(p.M - 1) * p.ldc + p.Ncol) * 4;
+      p.c_bytes = c_bytes < (1LL << 31) ? (uint32_t)c_bytes : 0u;
     }
   }
   if (f.sk_grid > 0) {
