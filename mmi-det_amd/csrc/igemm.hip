@@ -1286,6 +1286,16 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
     g.sk_grid = slots;
     return g;
   }
+  // short K on many rows (the 1x1 convs): with the uniform-tap loaders the 64x64 tile no longer pays more address
+  // arithmetic per MFMA than the wide ones, and its finer grid wins 10-20 % stand-alone (tools/sweep_tiles.py)
+  // (in the step: 126.7 -> 125.8 ms; MMIDET_SHORTK_TILE=0 restores plan_tiles' choice)
+  static const int shortk_tile = getenv("MMIDET_SHORTK_TILE") ? atoi(getenv("MMIDET_SHORTK_TILE")) : 64;
+  if (shortk_tile == 64 && g_gemm_prec == 0 && g_uniform_loaders && nk <= 64 && Ncol <= 1024 && M >= 8192) {
+    f.bm = f.bn = 64;
+    f.mtiles = cdiv(M, 64);
+    f.ntiles = cdiv(Ncol, 64);
+    return f;
+  }
   // short K, or too little work per workgroup for stream-K: one workgroup per tile with the tile shrunk until the grid has
   // two workgroups per CU (plan_tiles).  Finer 64x64 tiles win 10-16 % on the 1x1 layers stand-alone
   // (profiles/r01_tile_sweep_short_k.txt) but nothing inside the step, where the other lane fills the tail; always taking the
