@@ -911,9 +911,12 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     tow = rem - toh * p.Wo;
   }
   // wave (j & 3) writes the table of slab j (lanes 0..BK-1), then moves its cursor four slabs on
+  // 1x1 stride-1 layers: x rows are as linear in the pixel index as the dy rows, so they take the same re-based resource
+  // and no table at all
+  const bool lin1w = TAB && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;  // uniform
   auto build_table = [&](int j) {
     if constexpr (TAB) {
-      if (wave == (j & 3) && lane < BK) {
+      if (!lin1w && wave == (j & 3) && lane < BK) {
         uint2 e = {0u, 0xFFFFFFFFu};
         if (tpix < kend) {
           const int ih0 = toh * p.stride - p.pad, iw0 = tow * p.stride - p.pad;
@@ -989,6 +992,14 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   };
   auto load_b_row = [&](int i) {
     if constexpr (TAB) {
+      if (lin1w) {
+        const int64_t left = (int64_t)(kend - k0cur) * p.ldx * 4;
+        const __amdgpu_buffer_rsrc_t srd_xs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.X + (int64_t)k0cur * p.ldx), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0, 0x00020000);
+        const uint32_t voff = b_ok[0] ? (uint32_t)(((bkr + RPB * i) * p.ldx + b_ci[0]) * 4) : OOB;
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_xs, voff, 0, 0));
+        return;
+      }
       const uint2 e = ptab[tab_sel][bkr + RPB * i];
       const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe((int)e.y, b_tapbit, 1);  // -1: this thread's tap leaves the image
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
