@@ -1141,7 +1141,9 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     __builtin_amdgcn_sched_barrier(0);
     if (MMI_WGRAD_STAGES == 1) __syncthreads();
     lstore(MMI_WGRAD_STAGES == 2 ? ((ks + 1) & 1) : 0);
-    build_table(ks + 2);  // read during the next iteration (its loads are those of slab ks + 2); shares a buffer with slab ks
+    // read during the next iteration (its loads are those of slab ks + 2); shares a buffer with slab ks.  (Built at the top of
+    // the iteration instead, in the shadow of the MFMAs, it costs 3-9 %: VALU next to the MFMA stream again.)
+    build_table(ks + 2);
     __syncthreads();
   }
 
@@ -1203,7 +1205,8 @@ struct FwdPlan {
   int bm, bn, mtiles, ntiles;
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
-int g_uniform_loaders = 1;  // mmi_set_uniform_loaders (A/B switch): 1 = use the uniform-tap loaders where they apply
+// mmi_set_uniform_loaders / MMIDET_UNIFORM_LOADERS=0 (A/B switch): 1 = use the uniform-tap loaders where they apply
+int g_uniform_loaders = getenv("MMIDET_UNIFORM_LOADERS") ? atoi(getenv("MMIDET_UNIFORM_LOADERS")) : 1;
 int g_gemm_prec = 0;  // mmi_set_gemm_precision: 0 = exact fp32 MFMA, 1 = split-bf16 products for forward-layout GEMMs
 int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
 FwdPlan plan_tiles(int64_t M, int Ncol) {
