@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R, os.path.join(R, 'mmi-det_amd'), os.path.join(R, 'tests')]
 from mmidet_hip import lib  # noqa: E402
 from oracle import portable_init  # noqa: E402

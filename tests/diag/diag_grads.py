@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, 'mmi-det_amd'), os.path.join(REPO, 'tests')]
 from conftest import tiny_cfg  # noqa: E402
 from oracle import portable_init  # noqa: E402

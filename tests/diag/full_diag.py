@@ -6,7 +6,7 @@ import sys
 import torch
 import yaml
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [R, os.path.join(R, 'mmi-det_amd'), os.path.join(R, 'tests')]
 from mmidet_hip import lib  # noqa: E402
 from models.yolo_test import Model  # noqa: E402

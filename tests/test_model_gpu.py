@@ -86,7 +86,7 @@ def test_train_step_matches_reference_fixture_and_oracle(kind):
 def test_every_parameter_gradient_vs_oracle(kind):
     """Elementwise gradient parity for every parameter.  Uses batch seed 2: with seed 1 (the fixture batch) one SPP
     max-pool window of the IR stream holds two values 1 ulp apart, the arg-max flips between any two fp32 evaluation
-    orders and moves ~3e-3 of that stream's gradient (tools/diag_grads.py shows it; fp32-vs-fp64 CPU runs flip too on
+    orders and moves ~3e-3 of that stream's gradient (tests/diag/diag_grads.py shows it; fp32-vs-fp64 CPU runs flip too on
     other seeds).  Norm-level parity on the fixture batch is asserted in the test above."""
     from oracle import portable_init
     from oracle.ref_loss import ComputeLoss as OLoss

@@ -89,7 +89,7 @@ def test_train_step_split_bf16_matches_oracle(kind, split_bf16):
     close(ig, io, what='items', tol=1e-4)
     # Gradients are where the split arithmetic shows: a GEMM result is off by ~5e-6, predictions by ~3e-5, but ~150 layers of
     # backward (BatchNorm's mean-subtraction cancels leading digits) amplify that to ~1e-3 per parameter gradient (fp32 MFMA
-    # path: 5e-5, tools/b3_diag.py).  That is why the mode is opt-in and not the benchmarked default.
+    # path: 5e-5, tests/diag/b3_diag.py).  That is why the mode is opt-in and not the benchmarked default.
     og = dict(o.named_parameters())
     errs = sorted(rel_err(p.grad, og[n].grad) for n, p in m.named_parameters()
                   if og[n].grad is not None and p.grad is not None and float(og[n].grad.norm()) > 1e-5)
