@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
           for (int r = 0; r < 16; ++r) {
             const float v = acc[i][j][r] + bv;
             s1 += v;
-            s2 += v * v;
+            s2 = __builtin_fmaf(v, v, s2);  // (explicit, so that both epilogue forms round alike)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_c, voff,
                                                   (uint32_t)((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc) * 4u, 0);
           }
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
           const int row = m0 + lr;
           float v = acc[i][j][r] + bv;
           s1 += v;
-          s2 += v * v;
+          s2 = __builtin_fmaf(v, v, s2);
           if (!DGRAD && p.act != MMI_ACT_NONE) v = act_fwd(v, p.act);  // uniform; training never sets it (BN follows)
           if (!DGRAD && p.res != nullptr && cok && row < Mc) v += p.res[(int64_t)row * p.ldr + col];
           if (EPI && p.epi != MMI_EPI_NONE && cok && row < Mc) {  // uniform switch; 1x1 only, so `row` is the output row

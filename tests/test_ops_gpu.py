@@ -269,3 +269,37 @@ def test_build_targets_bit_exact(tag, bs, per):
         assert np.array_equal(torch.stack(idx[i]).cpu().numpy(), gfile['%s.idx%d' % (tag, i)])
         assert np.array_equal(tbox[i].cpu().numpy(), gfile['%s.tbox%d' % (tag, i)])
         assert np.array_equal(anch[i].cpu().numpy(), gfile['%s.anch%d' % (tag, i)])
+
+
+@pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (2, 21, 23, 32, 64, 3, 2), (2, 16, 16, 128, 256, 1, 1), (4, 40, 40, 128, 128, 3, 1),
+                                  (1, 33, 17, 96, 64, 3, 1)])
+def test_uniform_loaders_are_bit_identical_to_the_general_ones(case):
+    """mmi_set_uniform_loaders: the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders only change how a tile's
+    addresses are formed; the arithmetic and its order are those of the general cursor-based loaders, so y, dx and dw must be
+    equal bit for bit -- including zero padding at the borders, ragged tiles and the stride-2 parity classes."""
+    from mmidet_hip import lib, ops
+    N, H, W, Ci, Co, k, s = case
+    d = dev()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, generator=g).to(d)
+    w = (torch.randn(Co, k, k, Ci, generator=g) / (k * k * Ci) ** 0.5).to(d)
+    desc = ops._desc((N, H, W, Ci), Co, k, s, Ci, Co)
+    dy = torch.randn(N, desc.Ho, desc.Wo, Co, generator=g).to(d)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.set_uniform_loaders(on)
+            y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+            part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co + 64 * 2 * Co, device=d)
+            nb = lib.conv_wgrad_workspace(desc)
+            ws = torch.empty(max(nb // 4, 1), device=d)
+            ops.conv_fwd(x, w, None, y, part, desc, st)
+            ops.conv_dgrad(dy, w, dx, desc, st)
+            lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
+            torch.cuda.synchronize()
+            outs.append((y, dx, dw, part[:lib.conv_fwd_row_blocks(desc) * 2 * Co].clone()))
+    finally:
+        lib.set_uniform_loaders(1)
+    for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dw', 'BN statistics partials')):
+        assert torch.equal(a, b), what
