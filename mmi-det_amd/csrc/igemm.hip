@@ -1553,6 +1553,8 @@ extern "C" int mmi_linear_fwd_fused(const float* x, const float* w, const float*
   p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = 1; p.KW = 1;
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = 1; p.pad = 0; p.Ktot = d->Cin; p.ldb = p.Ktot;
+  if (p.epi == MMI_EPI_NONE)  // a plain Linear: the convolution instantiation (buffer-store epilogue, fewer registers)
+    return launch_igemm<false, false>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
   return launch_igemm<false, true>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1568,6 +1570,8 @@ extern "C" int mmi_linear_dgrad_fused(const float* dy, const float* w, float* dx
   p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = 1; p.KW = 1;
   p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
   p.stride = 1; p.pad = 0; p.Ktot = d->Cout; p.ldb = d->Cin;
+  if (p.epi == MMI_EPI_NONE)
+    return launch_igemm<true, false>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
   return launch_igemm<true, true>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
