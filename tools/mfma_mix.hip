@@ -2,6 +2,7 @@
 // filler instructions of one kind issued after every v_mfma_f32_32x32x2_f32, at 3 waves per SIMD (the conv kernels'
 // occupancy).  Everything is volatile inline asm, so program order is issue order.  The conv kernel's K loop carries
 // about 2.3 VALU (a third of them 64-bit address arithmetic), 0.5 ds_read_b128 and 0.12 global loads per MFMA.
+// build: hipcc -O3 --offload-arch=gfx950 -Wno-unused-value -o tools/bin/mfma_mix tools/mfma_mix.hip   (output: profiles/r01_mfma_mix.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
