@@ -152,10 +152,34 @@ class Model(nn.Module):
             self._ir_streams[device] = s
         return s
 
+    def half(self):
+        """Reference callers switch inference to fp16 (test.py:66-68,107; detect_twostream.py:44-45,78-82) and the trainer
+        rounds the weights through fp16 once (`model.half().float()`, train.py:680).  The kernels compute in fp32, so here
+        half() rounds every floating parameter and buffer to its fp16 value IN PLACE (storage stays fp32: same values as
+        the reference's `.half().float()`) and marks the model's I/O as fp16: fp16 images are accepted and the detections
+        come back as fp16.  float() clears the mark."""
+        with torch.no_grad():
+            for t in list(self.parameters()) + list(self.buffers()):
+                if t.dtype == torch.float32:
+                    t.copy_(t.half().float())
+        self._io_half = True
+        return self
+
+    def float(self):
+        self._io_half = False
+        return super().float()
+
     def forward(self, x, x2, augment=False, profile=False):
         if augment:
             raise NotImplementedError('TTA is dead code in the reference too (yolo_test.py:149 drops x2)')
-        return self.forward_once(x, x2, profile)
+        io_half = getattr(self, '_io_half', False)
+        if x.dtype != torch.float32 or x2.dtype != torch.float32:
+            assert x.dtype == torch.float16 and io_half, 'inputs are fp32 (or fp16 after model.half())'
+            x, x2 = x.float(), x2.float()
+        det, comb = self.forward_once(x, x2, profile)
+        if io_half:
+            det = [t.half() for t in det] if self.training else (det[0].half(), [t.half() for t in det[1]])
+        return det, comb
 
     def forward_once(self, x, x2, profile=False):
         dev = x.device
