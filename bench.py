@@ -238,6 +238,21 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves.  This parent never touches the GPU
+        # (nothing above initialises HIP); the ranks are fresh child processes and rank 0's JSON line is relayed as is.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '2')
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     t_start = time.perf_counter()
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 from native code, so the real stdout
     # is parked on a private descriptor and fd 1 points at stderr until the result is written.
@@ -349,6 +364,12 @@ def main():
     t_enq = time.perf_counter() - t0      # host time to enqueue the K steps (the GPU may still be running)
     barrier()
     dt = time.perf_counter() - t0
+    enq_ranks = [t_enq / args.steps * 1e3]
+    if world > 1:                         # host enqueue per step of every rank: eight Python threads share the box's cores
+        te = torch.tensor([t_enq / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allte = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(allte, te)
+        enq_ranks = [float(x) for x in allte]
     timer.on = False
     roof_steps = args.steps
     if not args.no_roofline:
@@ -411,6 +432,7 @@ def main():
                        'launch_mode': ('eager, wgrad on a side stream' if not use_graph else 'whole-step hipGraph replay' if not ddp else
                                        'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
+                       'host_enqueue_ms_per_step_per_rank': [round(v, 2) for v in enq_ranks],
                        'loss': [round(float(v), 5) for v in items.tolist()]},
         }
         if not args.no_roofline:

@@ -21,10 +21,11 @@ _DEBUG = __import__('os').environ.get('MMIDET_DDP_DEBUG', '')
 
 
 class _Bucket:
-    __slots__ = ('flat', 'params', 'pending', 'work', 'launched')
+    __slots__ = ('flat', 'params', 'pending', 'work', 'launched', 'streams')
 
     def __init__(self, flat, params):
         self.flat, self.params, self.pending, self.work, self.launched = flat, params, len(params), None, False
+        self.streams = {}      # HIP streams that wrote one of this bucket's gradients this step (handle -> Stream)
 
 
 class GradReducer:
@@ -32,7 +33,10 @@ class GradReducer:
     the weight-gradient kernels write straight into the parameter's bucket view (ops.GRAD_SLOTS) and autograd adopts that
     view as `.grad`; the remaining small gradients (BatchNorm/LayerNorm/bias vectors, pos_emb) are copied into their view by
     the grad-ready hook.  That removes a read-modify-write pass over 832 MB per step and lets TrainStep keep the
-    deferred-join wgrad overlap under data parallelism (nobody reads a weight gradient during backward)."""
+    deferred-join wgrad overlap under data parallelism (nobody reads a weight gradient during backward).
+    Direct mode holds only while every backward starts with `.grad is None` (the kernels OVERWRITE the bucket view; autograd
+    would then add the view to itself): prepare() enforces it, and gradient accumulation over several backward passes needs
+    set_direct(False) (TrainStep switches by itself), where autograd accumulates into the bucket views as usual."""
 
     def __init__(self, params, bucket_mb=256, process_group=None, direct=None):
         self.pg = process_group
@@ -55,18 +59,16 @@ class GradReducer:
                 self._of[p] = b
                 if _DEBUG != 'nohooks':
                     p.register_post_accumulate_grad_hook(self._ready)
+        self._stale_ok = False   # .grad tensors left by zero(keep_grads=True) are leftovers, not gradients to accumulate onto
         self.enabled = True      # False while a hipGraph of forward+backward is captured/replayed: see reduce_now()
         self.cuda = params[0].is_cuda
-        self.direct = self.cuda if direct is None else (direct and self.cuda)
-        self._slot = {}
-        if self.direct:
-            from . import ops
-            self._ops = ops
-            for b in self.buckets:
-                for p in b.params:
-                    self._slot[p] = p.grad                      # the bucket view made by _make
-                    ops.GRAD_SLOTS[p.data_ptr()] = p.grad
-                    p.grad = None
+        self._slot = {p: p.grad for b in self.buckets for p in b.params}      # the bucket views made by _make
+        self.direct = False
+        from . import ops
+        self._ops = ops
+        # default: direct on the GPU; on the CPU (gloo tests) only on request -- the bookkeeping is the same, the kernels that
+        # write the slots are the caller's
+        self.set_direct(self.cuda if direct is None else direct)
         self.comm = torch.cuda.Stream(device=params[0].device) if self.cuda else None
         self.avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else dist.ReduceOp.SUM
 
@@ -81,32 +83,79 @@ class GradReducer:
             off += p.numel()
         return _Bucket(flat, params)
 
+    def set_direct(self, flag):
+        """Switch between the two gradient forms (see the class docstring).  Only between steps: the buckets are zeroed."""
+        flag = bool(flag)
+        if flag:
+            for p, slot in self._slot.items():
+                self._ops.GRAD_SLOTS[p.data_ptr()] = slot
+                p.grad = None
+        else:
+            for b in self.buckets:
+                b.flat.zero_()
+            for p, slot in self._slot.items():
+                self._ops.GRAD_SLOTS.pop(p.data_ptr(), None)
+                p.grad = slot
+        self._ops.SLOT_HANDED_OUT.clear()
+        self.direct = flag
+
     def broadcast_parameters(self, module, src=0):
         """Rank-0 weights/buffers to every rank once (what DDP's constructor does)."""
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src, group=self.pg)
 
     def prepare(self):
+        """Before every backward."""
         for b in self.buckets:
             b.pending, b.work, b.launched = len(b.params), None, False
+            b.streams.clear()
+        if self.direct:
+            # The kernels overwrite the slots and autograd must ADOPT them.  A `.grad` left over from the previous backward
+            # (a replayed graph keeps them: zero(keep_grads=True); a caller that skipped zero()) would make AccumulateGrad
+            # compute slot += alias-of-slot = 2*g and lose what was there.  Leftovers of zero(keep_grads=True) are dropped
+            # here; anything else means the caller is accumulating over several backward passes, which needs
+            # set_direct(False), and is told so instead of getting wrong numbers.
+            for p in self._slot:
+                if p.grad is not None:
+                    if not self._stale_ok:
+                        raise RuntimeError('GradReducer: a backward pass starts with .grad set and no zero() since the last '
+                                           'one; direct mode cannot accumulate gradients (call set_direct(False) first)')
+                    p.grad = None
+            self._stale_ok = False
+            self._ops.SLOT_HANDED_OUT.clear()
+
+    def _order_behind_writers(self, b):
+        """Make the comm stream wait for EVERY stream that wrote into this bucket: backward runs on two lane streams (RGB /
+        IR backbone) and a bucket mixes parameters of both, so the stream of the last-ready hook alone is not enough; plus
+        the wgrad side streams whose kernels write the slots directly (deferred join)."""
+        for st in b.streams.values():
+            self.comm.wait_stream(st)
+        if self.direct and _DEBUG != 'nosidewait':
+            for sd in self._ops.side_streams_in_flight():
+                self.comm.wait_stream(sd)
 
     def _launch(self, b):
         b.launched = True
         if _DEBUG == 'noreduce':
             return
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            sides = self._ops.side_streams_in_flight() if (self.direct and _DEBUG != 'nosidewait') else []
+            cur = torch.cuda.current_stream()      # finish() launches stragglers from the caller's stream
+            b.streams[cur.cuda_stream] = cur
             with torch.cuda.stream(self.comm):
-                self.comm.wait_event(ev)                      # the bucket's last gradient has been written
-                for sd in sides:                              # ... including weight gradients still running on a wgrad stream
-                    self.comm.wait_stream(sd)
+                self._order_behind_writers(b)
                 b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
         else:
+            self._order_behind_writers_host(b)
             b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
 
+    def _order_behind_writers_host(self, b):
+        """CPU tensors are written synchronously: nothing to wait for (the gloo tests override this to model side streams)."""
+
     def _ready(self, p):
+        b = self._of[p]
+        if self.cuda:
+            cur = torch.cuda.current_stream()          # the stream this gradient was written / accumulated on
+            b.streams[cur.cuda_stream] = cur
         if self.direct:
             slot = self._slot[p]
             if p.grad.data_ptr() != slot.data_ptr():          # produced elsewhere (small vectors): move it into the bucket
@@ -117,7 +166,6 @@ class GradReducer:
                 p.grad = slot.detach()
         if not self.enabled:
             return
-        b = self._of[p]
         b.pending -= 1
         if b.pending == 0 and not b.launched:
             self._launch(b)
@@ -147,6 +195,7 @@ class GradReducer:
         (keep_grads: a replayed graph rewrites the same views without going through autograd again)."""
         if self.direct:
             self._ops.SLOT_HANDED_OUT.clear()
+            self._stale_ok = keep_grads
             if not keep_grads:
                 for p in self._slot:
                     p.grad = None

@@ -8,6 +8,7 @@ from . import lib
 from .lib import ACT_LEAKY, ACT_NONE, ACT_SILU, ConvDesc  # noqa: F401
 
 _scratch = {}
+_retired = []     # workspaces replaced by a larger one: kept until the streams that may still use them have been joined
 
 
 def _stream():
@@ -20,6 +21,11 @@ def scratch(nfloats, device, slot=0, stream=None):
     key = (device, slot, _stream() if stream is None else stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            # A workspace of ANOTHER stream (stream=side) is allocated while the lane stream is current, so the caching
+            # allocator would hand its memory to the next lane-stream allocation the moment the last reference drops --
+            # while an earlier wgrad on the side stream may still be reducing into it.  Keep it until join_pending().
+            _retired.append(buf)
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
         _scratch[key] = buf
     return buf
@@ -186,6 +192,10 @@ def join_pending():
         cur.wait_stream(side)
     _pending_sides.clear()
     _pending.clear()
+    if _retired and not torch.cuda.is_current_stream_capturing():
+        for side in _side_streams.values():      # (per-layer-join mode included: every wgrad stream, once)
+            cur.wait_stream(side)
+        _retired.clear()
 
 
 class _ConvBnAct(Function):

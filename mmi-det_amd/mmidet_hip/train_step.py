@@ -98,6 +98,8 @@ class TrainStep:
         # wgrad overlap with ONE join after backward (ops.join_pending) instead of one per layer: allowed when nobody reads a
         # weight gradient during backward, i.e. .grad is None (adopted untouched by autograd) -- not with the data-parallel
         # flat buckets or gradient accumulation, which add into existing .grad tensors as soon as a layer is done.
+        if self.reducer is not None and self.reducer.direct and self.accumulate != 1:
+            self.reducer.set_direct(False)       # accumulation: autograd adds into the bucket views (ddp.GradReducer)
         direct = self.reducer is None or getattr(self.reducer, 'direct', False)
         defer = self.defer_join and direct and self.accumulate == 1 and ops.OVERLAP_WGRAD
         F2.advance_seed(imgs_u8.device)                                                 # new dropout masks this step
@@ -113,6 +115,13 @@ class TrainStep:
         reduce = reduce and self.reducer is not None
         if reduce:
             self.reducer.prepare()
+        if defer and self.reducer is None:
+            # Deferred join is only sound when autograd ADOPTS every weight gradient untouched: with a .grad already there
+            # AccumulateGrad would read dw on the lane stream while its wgrad stream may still be writing it.
+            stale = next((n for n, p in self._named_params() if p.grad is not None), None)
+            if stale is not None:
+                raise RuntimeError('TrainStep: %s.grad is set at the start of backward (zero_grad(set_to_none=True) was skipped); '
+                                   'the deferred-join wgrad overlap needs .grad to be None' % stale)
         ops.DEFER_JOIN = defer
         try:
             loss.sum().backward()                                                       # train.py:796
@@ -122,6 +131,11 @@ class TrainStep:
         if reduce:
             self.reducer.finish()                                                       # mean over ranks, as DDP
         return loss, items
+
+    def _named_params(self):
+        if getattr(self, '_np_cache', None) is None:
+            self._np_cache = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        return self._np_cache
 
     def _update(self, in_capture=False):
         """train.py:799-804: optimizer step, zero_grad, EMA."""
@@ -175,7 +189,7 @@ class TrainStep:
         # deferred-join form captures, but replays slower than without (158 vs 153 ms/step), so wgrad overlap is an
         # eager-mode feature and is off while capturing.
         prev = ops.OVERLAP_WGRAD
-        if self.model.two_streams:
+        if self.model.two_streams and not getattr(self, '_capture_keeps_wgrad_overlap', False):   # (tools/capture_probe.py)
             ops.OVERLAP_WGRAD = False
         try:
             self._capture_locked(imgs_u8, targets)

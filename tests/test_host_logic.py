@@ -8,7 +8,7 @@ import pytest
 import torch
 import yaml
 
-from conftest import CFG_DIR, GOLDEN, tiny_cfg
+from conftest import CFG_DIR, GOLDEN, REPO, tiny_cfg
 
 
 def test_state_dict_keys_match_reference_fixture():
@@ -128,3 +128,20 @@ def test_pack_qkv_keeps_parameters_and_state_dict():
     assert not torch.equal(sa.key_proj.weight, other.trans_blocks[0].sa.key_proj.weight)
     assert torch.equal(sa.que_proj.weight, other.trans_blocks[0].sa.que_proj.weight)
     assert torch.equal(sa.val_proj.weight, other.trans_blocks[0].sa.val_proj.weight)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent starts torch.distributed.run itself (and never touches
+    the GPU).  Without a GPU here both ranks stop at bench.py's 'needs an MI355X' assertion -- which is the evidence that two
+    ranks were started with RANK/WORLD_SIZE set and the parent relayed their failure."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs an MI355X') >= 2 or 'invalid device ordinal' in r.stderr, r.stderr[-3000:]
+    assert '--gpus 2 but WORLD_SIZE' not in r.stderr

@@ -228,6 +228,83 @@ def test_data_parallel_eager_writes_gradients_into_the_buckets():
         dist.destroy_process_group()
 
 
+def test_data_parallel_reducer_corner_cases():
+    """(a) gradient accumulation under the reducer, (b) a replayed graph followed by eager steps, (c) the
+    collective is ordered behind BOTH lane streams when wgrad runs on them -- each against the single-GPU step, world size 1."""
+    import os
+    import torch.distributed as dist
+    from mmidet_hip import ops
+    from mmidet_hip.ddp import GradReducer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29535')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+    prev_overlap = ops.OVERLAP_WGRAD
+    try:
+        # (a) accumulate = 2: two backward passes per optimizer step
+        m1, ts1, cfg = make(graph=False)
+        m2, ts2, _ = make(graph=False)
+        ts1.accumulate = ts2.accumulate = 2
+        red = ts2.reducer = GradReducer(list(m2.parameters()))
+        assert red.direct
+        for it in range(4):
+            imgs, tg = batch(cfg, 60 + it)
+            l1, _ = ts1.step(imgs, tg)
+            l2, _ = ts2.step(imgs, tg)
+            close(l1, l2, what='accumulate: loss %d' % it, tol=1e-4 if it < 2 else 6e-3)
+        assert not red.direct, 'TrainStep must leave direct mode when it accumulates'
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='accumulate: weights', tol=6e-3)
+        close(m1.model[-1].m[0].bias, m2.model[-1].m[0].bias, what='accumulate: detect bias', tol=6e-3)
+        ops.GRAD_SLOTS.clear()
+
+        # (b) graph replay (leaves .grad set: zero(keep_grads=True)), then eager steps on the same reducer
+        m1, ts1, cfg = make(graph=False)
+        m2, ts2, _ = make(graph=True)
+        red = ts2.reducer = GradReducer(list(m2.parameters()))
+        b0 = batch(cfg, 70)
+        for _ in range(2):
+            ts1.step(*b0)                                  # the capture's two warm-up steps
+        l1, _ = ts1.step(*b0)
+        l2, _ = ts2.step(*b0)
+        close(l1, l2, what='graph step', tol=1e-4)
+        assert any(p.grad is not None for p in m2.parameters())
+        ts2.use_graph = False
+        for it in range(2):
+            imgs, tg = batch(cfg, 71 + it)
+            l1, _ = ts1.step(imgs, tg)
+            l2, _ = ts2.step(imgs, tg)
+            close(l1, l2, what='eager after graph: loss %d' % it, tol=6e-3)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='eager after graph: weights', tol=6e-3)
+        ops.GRAD_SLOTS.clear()
+
+        # a second backward without zero() is refused in direct mode instead of doubling the gradient
+        m3, ts3, _ = make(graph=False)
+        red3 = ts3.reducer = GradReducer(list(m3.parameters()))
+        ts3._body(*b0)
+        with pytest.raises(RuntimeError, match='direct mode cannot accumulate'):
+            ts3._body(*b0)
+        ops.GRAD_SLOTS.clear()
+
+        # (c) wgrad on the lane streams (no side streams to wait for): poison the buckets, one backward, reduced == local
+        ops.OVERLAP_WGRAD = False
+        m1, ts1, cfg = make(graph=False)
+        m2, ts2, _ = make(graph=False)
+        red = ts2.reducer = GradReducer(list(m2.parameters()))
+        for b in red.buckets:
+            b.flat.fill_(float('nan'))
+        imgs, tg = batch(cfg, 80)
+        ts1._body(imgs, tg)
+        ts2._body(imgs, tg)
+        torch.cuda.synchronize()
+        for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+            if p.grad is not None:
+                assert torch.isfinite(q.grad).all(), n
+                close(q.grad, p.grad, what='lane-stream wgrad: ' + n, tol=2e-3)
+    finally:
+        ops.OVERLAP_WGRAD = prev_overlap
+        ops.GRAD_SLOTS.clear()
+        dist.destroy_process_group()
+
+
 def test_training_overfits_one_batch():
     """End-to-end sanity of the step (forward, loss, backward, fused SGD+EMA, BN running stats, warm-up schedule): 40 steps on
     one batch must bring the detection loss down steadily (measured 0.194 -> 0.141) and leave every parameter and buffer
