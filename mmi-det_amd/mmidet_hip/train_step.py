@@ -152,6 +152,9 @@ class TrainStep:
             self.reducer.zero(keep_grads=in_capture)                                    # grads are views of flat buckets
         else:
             self.optimizer.zero_grad(set_to_none=True)
+            if not self.fused:                  # parameters in no group (pos_emb, sobel_factor: SURVEY.md §9) still receive
+                for _, p in self._named_params():   # gradients; torch's optimizer only clears its own
+                    p.grad = None
 
     def step(self, imgs_u8, targets):
         if self.use_graph:
@@ -184,10 +187,14 @@ class TrainStep:
         return self._loss, self._items
 
     def _capture(self, imgs_u8, targets):
-        # The captured step keeps ONE level of stream forking: the twin backbone lanes (RGB/IR on two HIP streams).  The
-        # per-layer dgrad||wgrad fork inside a lane makes hipStreamEndCapture of this ROCm segfault (nested forks); the
-        # deferred-join form captures, but replays slower than without (158 vs 153 ms/step), so wgrad overlap is an
-        # eager-mode feature and is off while capturing.
+        # The captured step keeps ONE level of stream forking: the twin backbone lanes (RGB/IR on two HIP streams).
+        # Confirmed cause (tools/capture_probe.py, profiles/r02_capture_probe.txt): hipStreamEndCapture of ROCm 7.2 segfaults
+        # whenever a stream forked from a NON-origin capturing stream (lane -> its wgrad stream) is joined back into that
+        # stream; three plain torch kernels on main -> A -> B with B joined into A reproduce it, and the same B joined into
+        # the capture's origin stream is fine.  The per-layer dgrad||wgrad fork/join inside the IR lane is exactly that
+        # pattern (inside the RGB lane, which IS the origin, it is fine: "step:wgrad" passes).  The deferred-join form
+        # (wgrad streams joined once, into the origin) captures, but replays slower than no overlap (158 vs 153 ms/step),
+        # so wgrad overlap stays an eager-mode feature and is off while capturing.
         prev = ops.OVERLAP_WGRAD
         if self.model.two_streams and not getattr(self, '_capture_keeps_wgrad_overlap', False):   # (tools/capture_probe.py)
             ops.OVERLAP_WGRAD = False

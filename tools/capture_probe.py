@@ -63,7 +63,7 @@ def torch_pattern(name):
                     with torch.cuda.stream(C):
                         yc = work(ya + 1)
                 ya2 = work(ya)
-                if name == 'nested_join_to_origin':
+                if name in ('nested_join_to_origin', 'wait_on_idle_outside_stream'):
                     pass                                          # B is joined by the origin below, not by its parent lane
                 elif name == 'nested_two_children_join_all':
                     A.wait_stream(b)
@@ -74,7 +74,7 @@ def torch_pattern(name):
                     if yc is not None:
                         A.wait_stream(C)
             main.wait_stream(A)
-            if name == 'nested_join_to_origin':
+            if name in ('nested_join_to_origin', 'wait_on_idle_outside_stream'):
                 main.wait_stream(b)
             if name == 'wait_on_idle_outside_stream':
                 main.wait_stream(idle)                            # a stream that is NOT part of the capture
@@ -123,6 +123,8 @@ def step_pattern(name):
 
 def main():
     if len(sys.argv) > 1:
+        import faulthandler
+        faulthandler.enable()                      # a SIGSEGV prints the Python frame it happened under
         name = sys.argv[1]
         (step_pattern if name.startswith('step:') else torch_pattern)(name)
         return
@@ -134,8 +136,8 @@ def main():
             err = ''
             if r.returncode != 0:
                 lines = [l for l in r.stderr.strip().splitlines() if l.strip()]
-                key = [l for l in lines if 'Error' in l or 'error' in l or 'Fatal' in l or 'HIP' in l]
-                err = ' | '.join((key or lines)[-3:])[:400]
+                key = [l.strip() for l in lines if 'Error' in l or 'error' in l or 'Fatal' in l or 'HIP' in l or 'File "' in l]
+                err = ' | '.join((key or lines)[:3])[:400]
             print('%-34s rc=%-4d %s %s' % (name, r.returncode, tail, err), flush=True)
         except subprocess.TimeoutExpired:
             print('%-34s TIMEOUT' % name, flush=True)
