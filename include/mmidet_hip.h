@@ -50,7 +50,8 @@ typedef struct {
  *
  * Workspace (forward and dgrad): shapes whose tile count is a poor multiple of the chip run a stream-K schedule (equal
  * K-slab shares per resident workgroup, partial tiles folded in K order by the last contributor: deterministic) and need
- * mmi_conv_{fwd,dgrad}_workspace(d) bytes of device memory, 16-byte aligned; 0 means none (NULL is then fine).  The
+ * mmi_conv_{fwd,dgrad}_workspace(d) bytes of device memory, 16-byte aligned; 0 means none (NULL is then fine; the
+ * forward query also covers mmi_conv_bn_fwd's statistics fold and is never 0 for an implicit-GEMM shape).  The
  * buffer must be ZERO-FILLED when first handed over; every launch leaves it ready for the next one, of any shape, as
  * long as launches sharing a buffer are ordered on one stream. */
 int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d);
@@ -103,6 +104,24 @@ int mmi_set_tile_override(int bm, int bn);
 size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d);
 int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials, void* workspace,
                  size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+/* Training-mode Conv (models/common.py:116 `self.bn(self.conv(x))`): y = conv(x, w) AND the BatchNorm batch statistics
+ * finished in the same launch.  The epilogue writes the per-row-block partials as mmi_conv_fwd does; the workgroups that
+ * arrive last fold them (fixed order, fp64: run-to-run bit-identical) and write mean_invstd[0..C) = batch mean,
+ * mean_invstd[C..2C) = 1/sqrt(biased var + eps), update running_mean/var (torch semantics: unbiased variance, momentum)
+ * and increment *num_batches_tracked -- what mmi_bn_finalize would do in a launch of its own.  A layer that merges two
+ * convolutions of the reference over one input (C3's cv1 | cv2, models/common.py:645-650) passes both counters; they must
+ * be adjacent int64 words.  Workspace: mmi_conv_fwd_workspace(d) bytes, zero-filled when first handed over (the arrival
+ * counters live in it); always needed. */
+typedef struct {
+  float eps, momentum;
+  float* running_mean;            /* (C) or NULL (then running_var too) */
+  float* running_var;
+  int64_t* num_batches_tracked;   /* or NULL */
+  int64_t* num_batches_tracked2;  /* NULL, or num_batches_tracked + 1 */
+  float* mean_invstd;             /* out, (2C) */
+} mmi_bn_stats;
+int mmi_conv_bn_fwd(const float* x, const float* w, float* y, float* stat_partials, const mmi_bn_stats* bn, void* workspace,
+                    size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
 /* Inference form of Conv after Model.fuse() (models/common.py:124-125 fuseforward, utils/torch_utils.py:181-201):
  * y = act(conv(x, w) + bias) [+ residual]; act is an MMI_ACT_* code, residual (row stride ldr) may be NULL.  Same
  * workspace rule as mmi_conv_fwd. */
@@ -113,7 +132,10 @@ size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d);
 int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                    const mmi_conv_desc* d, void* stream);
 /* dw (OHWI) = sum over pixels dy^T x; dbias (nullable, Cout floats) = column sums of dy, taken from the same dy tiles
- * (the bias gradient of Detect / Linear costs no extra pass).  workspace holds split-K slabs; query its size first. */
+ * (the bias gradient of Detect / Linear costs no extra pass).  The workspace (query its size first; 16-byte aligned) holds
+ * per-tile arrival counters at its head -- ZERO-FILLED when first handed over, self-cleaning afterwards, launches sharing it
+ * ordered on one stream -- and the split-K slabs behind them: the workgroup that completes a tile's last split sums the
+ * splits in split order (deterministic), so no reduce launch follows. */
 size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d);
 int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                    const mmi_conv_desc* d, void* stream);
@@ -134,6 +156,12 @@ int mmi_bn_eval_stats(const float* running_mean, const float* running_var, int C
 /* out = act(gamma*(y-mean)*invstd+beta) [+ residual] */
 int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
                    const float* residual, int ldr, float* out, int ldo, int64_t rows, int C, int act, void* stream);
+/* The same with the output channels split over two tensors: [0, split) -> out (row stride ldo), [split, C) -> out1 (ldo1).
+ * C3's merged cv1 | cv2 convolution hands its first half to the bottleneck chain and writes the second straight into the
+ * buffer cv3 reads (models/common.py:650 `torch.cat` without the copy).  split = C: one output; split % 4 == 0. */
+int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                         const float* residual, int ldr, float* out, int ldo, float* out1, int ldo1, int split, int64_t rows,
+                         int C, int act, void* stream);
 /* backward, pass 1: partial column sums of dz and dz*xhat, dz = dout*act'(z): partials[pb][2][C], pb < nparts
  * (nparts = mmi_bn_bwd_parts(rows)). */
 int mmi_bn_bwd_parts(int64_t rows);
@@ -145,6 +173,16 @@ int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout, int ldd, c
 int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, const float* mean_invstd,
                          const float* gamma, const float* beta, const float* partials, int nparts, float* dy, int lddy,
                          float* dgamma, float* dbeta, int64_t rows, int C, int act, int frozen, void* stream);
+/* Both passes in one call, two launches: the reduce pass's last-arriving workgroups write dgamma / dbeta themselves (no
+ * fold launch in between; fixed fold order, fp64).  dout may come in two tensors split at channel `split` (gradient of the
+ * two outputs of mmi_bn_act_fwd_split), dgamma/dbeta then go to two parameter pairs; split = C: one of each (the *1
+ * arguments may be NULL).  Workspace: mmi_bn_act_bwd_workspace(rows, C) bytes, 16-byte aligned, zero-filled when first
+ * handed over (arrival counters at its head; self-cleaning; launches sharing it must be ordered on one stream). */
+size_t mmi_bn_act_bwd_workspace(int64_t rows, int C);
+int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
+                   const float* mean_invstd, const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
+                   float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C,
+                   int act, int frozen, void* stream);
 
 /* ---- Contour Enhancement Module special forms (models/common.py:751-911) --------------------------------------------
  * The 3->24 and 24->3 convs of AdaptiveModule3 are served by mmi_conv_fwd/dgrad/wgrad themselves (direct VALU kernels,

@@ -119,11 +119,13 @@ __device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
 // Streaming kernels: when the grid stride is a multiple of the C/V column groups (FIXED; every power-of-two C of the
 // model), a thread keeps its column group, so the per-channel parameters are loaded once and no 64-bit division runs per
 // element; otherwise the general index arithmetic is used.
+// Output channels [0, split) go to out (row stride ldo), channels [split, C) to out1 (ldo1): C3's merged cv1|cv2 conv hands
+// its first half to the bottleneck chain and writes the second half straight into the concat buffer (split = C: one output).
 template <int V, bool FIXED>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mi,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo,
-                                  int64_t rows, int C, int act) {
+                                  float* __restrict__ out1, int ldo1, int split, int64_t rows, int C, int act) {
   const int cv = C / V;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,8 +135,10 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const fl
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
     const float* py = y + r0 * ldy + c;
     const float* pr = res != nullptr ? res + r0 * ldr + c : nullptr;
-    float* po = out + r0 * ldo + c;
-    const int64_t sy = dr * ldy, sr = dr * ldr, so = dr * ldo;
+    const bool hi = c >= split;
+    const int ldo_ = hi ? ldo1 : ldo;
+    float* po = (hi ? out1 + (c - split) : out + c) + r0 * ldo_;
+    const int64_t sy = dr * ldy, sr = dr * ldr, so = dr * ldo_;
 #pragma unroll 2
     for (int64_t r = r0; r < rows; r += dr, py += sy, po += so) {
       const Vec<V> yy = ldv<V>(py);
@@ -165,18 +169,29 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const fl
 #pragma unroll
       for (int k = 0; k < V; ++k) o.v[k] += rr.v[k];
     }
-    stv<V>(out + r * ldo + c, o);
+    stv<V>(c >= split ? out1 + r * ldo1 + (c - split) : out + r * ldo + c, o);
   }
 }
 
-// backward pass 1: block = (64-channel group, rows part); threads = (64/V channel lanes) x row lanes
+// backward pass 1: block = (64-channel group, rows part); threads = (64/V channel lanes) x row lanes.  dout may come in two
+// tensors split at channel `split` (see bn_act_fwd_kernel).  With fold.cnt != null the workgroup that arrives last
+// (stat_arrive, common.h) also produces dbeta / dgamma, so the pass needs no "finalize" launch behind it.
+struct BnSplitOut {
+  float* dgamma0;
+  float* dbeta0;
+  float* dgamma1;
+  float* dbeta1;
+};
 template <int V>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
+                                     const float* __restrict__ dout1, int ldd1, int split,
                                      const float* __restrict__ mi, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ partials, int64_t rows, int C,
-                                     int act, int64_t rows_per_part) {
+                                     int act, int64_t rows_per_part, StatFold fold, BnSplitOut o) {
   constexpr int CL = 64 / V, RL = 256 / CL;
   __shared__ float red[2][RL][64];
+  __shared__ double redd[512];
+  __shared__ int flag;
   const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
   const int c = blockIdx.x * 64 + cl * V;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_part;
@@ -186,8 +201,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const
   for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
   if (c < C) {
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
+    const bool hi = c >= split;
+    const float* pd = hi ? dout1 + (c - split) : dout + c;
+    const int ldd_ = hi ? ldd1 : ldd;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
-      const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(dout + r * ldd + c);
+      const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(pd + r * ldd_);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const float xh = (yy.v[k] - m.v[k]) * is.v[k];
@@ -209,7 +227,16 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const
 #pragma unroll
     for (int i = 0; i < RL; ++i) acc += red[s][i][cc];
     const int col = blockIdx.x * 64 + cc;
-    if (col < C) partials[((int64_t)blockIdx.y * 2 + s) * C + col] = acc;
+    if (col < C) st_agent(partials + ((int64_t)blockIdx.y * 2 + s) * C + col, acc);
+  }
+  if (fold.cnt == nullptr) return;  // uniform
+  double t1, t2;
+  if (!stat_arrive<64>(fold, blockIdx.y, blockIdx.x, blockIdx.x * 64, redd, &flag, t1, t2)) return;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && col < C) {
+    const bool hi = col >= split;
+    (hi ? o.dbeta1 + (col - split) : o.dbeta0 + col)[0] = (float)t1;
+    (hi ? o.dgamma1 + (col - split) : o.dgamma0 + col)[0] = (float)t2;
   }
 }
 
@@ -281,9 +308,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
 
 template <int V, bool FIXED>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
+                                    const float* __restrict__ dout1, int ldd1, int split,
                                     const float* __restrict__ mi, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, float* __restrict__ dy, int lddy, int64_t rows, int C,
+                                    const float* __restrict__ beta, BnSplitOut gs, float* __restrict__ dy, int lddy, int64_t rows, int C,
                                     int act, int frozen) {
   const int cv = C / V;
   const float inv_rows = 1.0f / (float)rows;
@@ -292,12 +319,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const 
   if (FIXED) {
     const int64_t r0 = e0 / cv, dr = stride / cv;
     const int c = (int)(e0 - r0 * cv) * V;
+    const bool hi = c >= split;
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
-                 dg = ldv<V>(dgamma + c), db = ldv<V>(dbeta + c);
+                 dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
+    const int ldd_ = hi ? ldd1 : ldd;
     const float* py = y + r0 * ldy + c;
-    const float* pd = dout + r0 * ldd + c;
+    const float* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
     float* po = dy + r0 * lddy + c;
-    const int64_t sy = dr * ldy, sd = dr * ldd, so = dr * lddy;
+    const int64_t sy = dr * ldy, sd = dr * ldd_, so = dr * lddy;
 #pragma unroll 2
     for (int64_t r = r0; r < rows; r += dr, py += sy, pd += sd, po += so) {
       const Vec<V> yy = ldv<V>(py), dd = ldv<V>(pd);
@@ -317,9 +346,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const 
   for (int64_t e = e0; e < total; e += stride) {
     const int64_t r = e / cv;
     const int c = (int)(e - r * cv) * V;
-    const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(dout + r * ldd + c), m = ldv<V>(mi + c),
-                 is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c), dg = ldv<V>(dgamma + c),
-                 db = ldv<V>(dbeta + c);
+    const bool hi = c >= split;
+    const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(hi ? dout1 + r * ldd1 + (c - split) : dout + r * ldd + c), m = ldv<V>(mi + c),
+                 is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
+                 dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
     Vec<V> o;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -412,18 +442,19 @@ extern "C" int mmi_bn_eval_stats(const float* running_mean, const float* running
   return MMI_OK;
 }
 
-extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
-                              const float* residual, int ldr, float* out, int ldo, int64_t rows, int C, int act,
-                              void* stream) {
+extern "C" int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                                    const float* residual, int ldr, float* out, int ldo, float* out1, int ldo1, int split,
+                                    int64_t rows, int C, int act, void* stream) {
   MMI_CHECK_ARG(y && mean_invstd && gamma && beta && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
-  MMI_CHECK_ARG(ldy >= C && ldo >= C && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
+  MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (out1 && split % 4 == 0 && ldo1 >= C - split)), "mmi_bn_act_fwd: bad channel split");
+  MMI_CHECK_ARG(ldy >= C && ldo >= split && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0}, {y, out, residual, mean_invstd, gamma, beta});
+  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0, split < C ? ldo1 : 0}, {y, out, residual, mean_invstd, gamma, beta, split < C ? out1 : nullptr});
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_FWD(V_, F_) \
   hipLaunchKernelGGL((bn_act_fwd_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta, residual, \
-                     ldr, out, ldo, rows, C, act)
+                     ldr, out, ldo, out1, ldo1, split, rows, C, act)
   if (vec && fixed) LAUNCH_FWD(4, true);
   else if (vec) LAUNCH_FWD(4, false);
   else if (fixed) LAUNCH_FWD(1, true);
@@ -431,6 +462,12 @@ extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd,
 #undef LAUNCH_FWD
   MMI_CHECK_LAUNCH("mmi_bn_act_fwd");
   return MMI_OK;
+}
+
+extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                              const float* residual, int ldr, float* out, int ldo, int64_t rows, int C, int act,
+                              void* stream) {
+  return mmi_bn_act_fwd_split(y, ldy, mean_invstd, gamma, beta, residual, ldr, out, ldo, nullptr, 0, C, rows, C, act, stream);
 }
 
 extern "C" int mmi_bn_bwd_parts(int64_t rows) {
@@ -446,18 +483,43 @@ extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout,
   const int64_t rpp = (rows + nparts - 1) / nparts;
   const dim3 grid(cdiv(C, 64), nparts);
   hipStream_t s = (hipStream_t)stream;
+  const StatFold nofold{};
+  const BnSplitOut noout{};
   if (C <= 8)
     hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel, dim3(1, nparts), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp);
   else if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, beta, partials,
-                       rows, C, act, rpp);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+                       beta, partials, rows, C, act, rpp, nofold, noout);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, beta, partials,
-                       rows, C, act, rpp);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+                       beta, partials, rows, C, act, rpp, nofold, noout);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_reduce");
   return MMI_OK;
 }
+
+namespace {
+int launch_apply(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
+                 const float* mean_invstd, const float* gamma, const float* beta, const BnSplitOut& gs, float* dy, int lddy,
+                 int64_t rows, int C, int act, int frozen, hipStream_t s) {
+  const bool two = split < C;
+  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0},
+                          {y, dout, dy, mean_invstd, gamma, beta, gs.dgamma0, gs.dbeta0, two ? dout1 : nullptr, two ? gs.dgamma1 : nullptr,
+                           two ? gs.dbeta1 : nullptr});
+  bool fixed;
+  const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
+#define LAUNCH_APPLY(V_, F_) \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
+                     gamma, beta, gs, dy, lddy, rows, C, act, frozen)
+  if (vec && fixed) LAUNCH_APPLY(4, true);
+  else if (vec) LAUNCH_APPLY(4, false);
+  else if (fixed) LAUNCH_APPLY(1, true);
+  else LAUNCH_APPLY(1, false);
+#undef LAUNCH_APPLY
+  MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply");
+  return MMI_OK;
+}
+}  // namespace
 
 extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, const float* mean_invstd,
                                     const float* gamma, const float* beta, const float* partials, int nparts, float* dy,
@@ -468,19 +530,52 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
-  const bool vec = vec_ok(C, {ldy, ldd, lddy}, {y, dout, dy, mean_invstd, gamma, beta, dgamma, dbeta});
-  bool fixed;
-  const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
-#define LAUNCH_APPLY(V_, F_) \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma, \
-                     beta, dgamma, dbeta, dy, lddy, rows, C, act, frozen)
-  if (vec && fixed) LAUNCH_APPLY(4, true);
-  else if (vec) LAUNCH_APPLY(4, false);
-  else if (fixed) LAUNCH_APPLY(1, true);
-  else LAUNCH_APPLY(1, false);
-#undef LAUNCH_APPLY
-  MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply");
-  return MMI_OK;
+  const BnSplitOut gs{dgamma, dbeta, nullptr, nullptr};
+  return launch_apply(y, ldy, dout, ldd, nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+}
+
+// One-call BatchNorm(+activation) backward: reduce (whose last-arriving workgroups write dgamma / dbeta) + apply = two
+// launches instead of three.  Workspace layout: arrival counters | partials[nparts][2][C] | l1[ngroups][2][C].
+extern "C" size_t mmi_bn_act_bwd_workspace(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int nparts = mmi_bn_bwd_parts(rows);
+  const int ngroups = cdiv(nparts, stat_group_size(nparts));
+  return (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int) + ((size_t)nparts + ngroups) * 2 * C * sizeof(float);
+}
+
+extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
+                              const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
+                              size_t workspace_bytes, float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
+                              float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
+  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && workspace && dy && dgamma && dbeta && rows > 0 && C > 0,
+                "mmi_bn_act_bwd: bad arguments");
+  MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (dout1 && dgamma1 && dbeta1 && split % 4 == 0 && ldd1 >= C - split && C > 8)),
+                "mmi_bn_act_bwd: bad channel split");
+  MMI_CHECK_ARG(workspace_bytes >= mmi_bn_act_bwd_workspace(rows, C) && ((uintptr_t)workspace & 15) == 0, "mmi_bn_act_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nparts = mmi_bn_bwd_parts(rows);
+  const int64_t rpp = (rows + nparts - 1) / nparts;
+  float* partials = (float*)((char*)workspace + (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int));
+  const BnSplitOut gs{dgamma, dbeta, dgamma1, dbeta1};
+  const int nct = cdiv(C, 64), G = stat_group_size(nparts), ngroups = cdiv(nparts, G);
+  if (C <= 8 || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS) {  // the CEM's 3-channel map: one thread per row, separate fold
+    if (int e = mmi_bn_act_bwd_reduce(y, ldy, dout, ldd, mean_invstd, gamma, beta, partials, rows, C, act, stream)) return e;
+    MMI_CHECK_ARG(split == C, "mmi_bn_act_bwd: channel split unsupported for this shape");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, dgamma, dbeta, 1);
+    MMI_CHECK_LAUNCH("mmi_bn_act_bwd(finalize)");
+  } else {
+    StatFold f{partials, partials + (size_t)nparts * 2 * C, (int*)workspace, nparts, C, nct, G};
+    const dim3 grid(nct, nparts);
+    const bool two = split < C;
+    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, mean_invstd, gamma, beta, two ? dout1 : nullptr}))
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+                         partials, rows, C, act, rpp, f, gs);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+                         partials, rows, C, act, rpp, f, gs);
+    MMI_CHECK_LAUNCH("mmi_bn_act_bwd(reduce)");
+  }
+  return launch_apply(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
 }
 
 extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {

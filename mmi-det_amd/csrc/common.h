@@ -54,6 +54,106 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// ---- last-arriver fold of per-row-block column statistics (BatchNorm forward statistics out of the conv epilogue,
+// dgamma/dbeta out of the BN backward reduce pass) --------------------------------------------------------------------
+// Every workgroup of the producing kernel writes one row of part[row][2][C] (two sums per channel, its BNC columns starting
+// at c0) with agent-scope stores and then calls stat_arrive().  Rows are grouped G at a time: the LAST workgroup to arrive
+// in a group folds the group's rows into l1[group][2][C]; the last GROUP to finish folds l1 and returns true with the
+// column totals (fp64) in threads t < BNC.  Nobody waits for anybody; the fold order is fixed (row order), so the result
+// does not depend on who arrives last: run-to-run bit-identical, no float atomics, and no separate "finalize" launch.
+// cnt[ngroups * nct + nct] arrival counters: zero before the launch, zero again after it (the electing thread resets).
+struct StatFold {
+  float* part;  // [nrows][2][C]
+  float* l1;    // [ngroups][2][C]
+  int* cnt;
+  int nrows, C, nct, G;
+};
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// fold rows [r0, r1) of src[row][2][C], columns [c0, c0 + BNC): totals in threads t < BNC (red: LDS, 2 * 256 doubles)
+template <int BNC>
+__device__ __forceinline__ void stat_fold_rows(const float* src, int r0, int r1, int C, int c0, double* red, double& s1, double& s2) {
+  constexpr int RL = 256 / BNC;
+  const int t = threadIdx.x, col = t % BNC, rl = t / BNC;
+  double a = 0.0, b = 0.0;
+  if (c0 + col < C) {
+    constexpr int U = 4;  // the loads of one round are independent: a round costs one memory latency, not U
+    const float* base = src + c0 + col;
+    for (int r = r0 + rl; r < r1; r += RL * U) {
+      float va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + RL * u;
+        const bool ok = rr < r1;
+        const int64_t o = (int64_t)(ok ? rr : r) * 2 * C;
+        va[u] = ld_agent(base + o);
+        vb[u] = ld_agent(base + o + C);
+        if (!ok) va[u] = vb[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a += (double)va[u];
+        b += (double)vb[u];
+      }
+    }
+  }
+  __syncthreads();  // red may still be read by the previous fold
+  red[(0 * RL + rl) * BNC + col] = a;
+  red[(1 * RL + rl) * BNC + col] = b;
+  __syncthreads();
+  s1 = s2 = 0.0;
+  if (t < BNC) {
+#pragma unroll
+    for (int i = 0; i < RL; ++i) {
+      s1 += red[(0 * RL + i) * BNC + t];
+      s2 += red[(1 * RL + i) * BNC + t];
+    }
+  }
+}
+
+// all 256 threads of the workgroup, after its row `row` (columns of tile `ct`) has been stored with st_agent()
+template <int BNC>
+__device__ __forceinline__ bool stat_arrive(const StatFold& f, int row, int ct, int c0, double* red, int* flag, double& s1, double& s2) {
+  const int t = threadIdx.x;
+  const int ngroups = (f.nrows + f.G - 1) / f.G;
+  const int g = row / f.G, r0 = g * f.G, r1 = min(r0 + f.G, f.nrows);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed (they are write-through)
+  __syncthreads();
+  if (t == 0) {
+    int* c = f.cnt + g * f.nct + ct;
+    const int last = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r1 - r0 - 1;
+    if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return false;  // uniform
+  stat_fold_rows<BNC>(f.part, r0, r1, f.C, c0, red, s1, s2);
+  if (t < BNC && c0 + t < f.C) {
+    st_agent(f.l1 + ((int64_t)g * 2 + 0) * f.C + c0 + t, (float)s1);
+    st_agent(f.l1 + ((int64_t)g * 2 + 1) * f.C + c0 + t, (float)s2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (t == 0) {
+    int* c = f.cnt + ngroups * f.nct + ct;
+    const int last = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+    if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return false;
+  stat_fold_rows<BNC>(f.l1, 0, ngroups, f.C, c0, red, s1, s2);
+  return true;
+}
+constexpr int MMI_STAT_GROUP = 32;            // rows per group (raised for very long lists so that ngroups <= 1024)
+constexpr int MMI_STAT_MAX_COUNTERS = 16384;  // ints reserved for the arrival counters in a workspace
+static inline int stat_group_size(int nrows) {
+  int g = MMI_STAT_GROUP;
+  while ((nrows + g - 1) / g > 1024) g *= 2;
+  return g;
+}
+
 // ---- counter-based dropout: keep iff hash(seed, index) >= p * 2^32 (tokens.hip kernels and the Linear epilogues) ----
 __device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;

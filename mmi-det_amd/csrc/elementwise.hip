@@ -171,8 +171,10 @@ __global__ void maxpool5_kernel(const float* __restrict__ src, int lds, float* _
   }
 }
 
-// SPP backward: thread = one (pixel, channel, pool k in {5,9,13}); routes dcat[..,(1+k)C+c] to the first arg-max of the
-// window of x (row-major scan, strict >, as ATen's max_pool2d) with a float atomic (few colliding adders).
+// SPP backward, fallback for maps too large for the LDS-tiled form below (more than ~44 x 44 positions, i.e. P5 of a
+// > 1400 x 1400 input): thread = one (pixel, channel, pool k in {5,9,13}); routes dcat[..,(1+k)C+c] to the first arg-max of
+// the window of x (row-major scan, strict >, as ATen's max_pool2d) with a float atomic -- the one place left where two
+// runs may differ in the last bit.
 __global__ void spp_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat, int ldd,
                                float* __restrict__ dx, int lddx, int N, int H, int W, int C) {
   const int64_t total = (int64_t)N * H * W * C * 3;
@@ -205,8 +207,10 @@ __global__ void spp_bwd_kernel(const float* __restrict__ x, int ldx, const float
 // SPP backward, tiled form: one workgroup = one image x CG channels with the whole H x W map in LDS.  The arg-max of a
 // (2r+1)^2 window with ATen's tie rule (first maximum in row-major order) is separable: per row the first column holding the
 // row-window maximum, then the first row holding the maximum of those -- 2(2r+1) compares instead of (2r+1)^2, all from
-// LDS; the three pools' gradients and the identity branch are summed in an LDS accumulator (LDS float atomics: a handful of
-// colliding adders) and written once, coalesced.
+// LDS.  Routing is a GATHER, so the result is run-to-run bit-identical (no float atomics): every output pixel records its
+// arg-max position, then every input position sums, in row-major order, the gradients of the outputs inside its window
+// that chose it; identity branch first, then the 5x5, 9x9 and 13x13 pools.
+constexpr int SPP_BYTES_PER_ELEM = 19;  // xs, rv, acc, gv (float) + rc (u8) + am (u16)
 template <int CG>
 __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat,
                                                             int ldd, float* __restrict__ dx, int lddx, int H, int W, int C) {
@@ -214,8 +218,10 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
   const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * CG, E = HW * CG;
   float* xs = reinterpret_cast<float*>(spp_smem);   // [HW][CG]
   float* rv = xs + E;                                // row-window maxima
-  float* acc = rv + E;                               // gradient accumulator
-  unsigned char* rc = reinterpret_cast<unsigned char*>(acc + E);   // column of the row-window maximum (W <= 255)
+  float* acc = rv + E;                               // gradient accumulator (element e is only ever touched by its owner thread)
+  float* gv = acc + E;                               // this pool's output gradients
+  unsigned short* am = reinterpret_cast<unsigned short*>(gv + E);   // arg-max position h*W+w of every output pixel (HW <= 65535)
+  unsigned char* rc = reinterpret_cast<unsigned char*>(am + E);     // column of the row-window maximum (W <= 255)
   const int t = threadIdx.x;
   for (int e = t; e < E; e += 256) {
     const int pix = e / CG, c = e - pix * CG;
@@ -240,7 +246,6 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
     __syncthreads();
     for (int e = t; e < E; e += 256) {
       const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
-      if (c0 + c >= C) continue;
       float best = -INFINITY;
       int bh = -1;
       for (int hh = max(h - rad, 0); hh <= min(h + rad, H - 1); ++hh) {
@@ -248,7 +253,19 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
         if (v > best || bh < 0) best = v, bh = hh;
       }
       const int bw = rc[(bh * W + w) * CG + c];
-      atomicAdd(acc + (bh * W + bw) * CG + c, dcat[((int64_t)n * HW + pix) * ldd + (1 + pk) * C + c0 + c]);
+      am[e] = (unsigned short)(bh * W + bw);
+      gv[e] = c0 + c < C ? dcat[((int64_t)n * HW + pix) * ldd + (1 + pk) * C + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int e = t; e < E; e += 256) {
+      const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
+      float s = acc[e];
+      for (int oh = max(h - rad, 0); oh <= min(h + rad, H - 1); ++oh)
+        for (int ow = max(w - rad, 0); ow <= min(w + rad, W - 1); ++ow) {
+          const int o = (oh * W + ow) * CG + c;
+          if (am[o] == (unsigned short)pix) s += gv[o];
+        }
+      acc[e] = s;
     }
     __syncthreads();
   }
@@ -410,10 +427,10 @@ extern "C" int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int 
   MMI_CHECK_ARG(x && dcat && dx && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && ldd >= 4 * C && lddx >= C,
                 "mmi_spp_pool_bwd: bad arguments");
   const int64_t rows = (int64_t)N * H * W;
-  {  // tiled form when the map fits in LDS with at least 4 channels per workgroup (13 bytes per map element)
-    const size_t per_c = (size_t)H * W * 13;
+  {  // tiled form when the map fits in LDS with at least 4 channels per workgroup
+    const size_t per_c = (size_t)H * W * SPP_BYTES_PER_ELEM;
     const int cg = per_c * 16 <= 150 * 1024 ? 16 : (per_c * 8 <= 150 * 1024 ? 8 : (per_c * 4 <= 150 * 1024 ? 4 : 0));
-    if (cg > 0 && W <= 255) {
+    if (cg > 0 && W <= 255 && H * W <= 65535) {
       const dim3 grid(cdiv(C, cg), N), block(256);
       const size_t lds = per_c * cg;
       hipStream_t s = (hipStream_t)stream;

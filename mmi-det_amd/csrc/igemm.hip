@@ -77,6 +77,17 @@ struct IgemmP {
   // uniform-tap loaders: byte extents of the A tensor (incl. the margin in front of it) and of the weights; of the output
   // (0: too large for 31-bit offsets, the epilogue keeps its pointer stores)
   uint32_t a_bytes, b_bytes, c_bytes;
+  // BatchNorm statistics finished inside this launch (mmi_conv_bn_fwd): the workgroups that arrive last fold the partial
+  // rows (stat_arrive, common.h) and write mean / 1/sqrt(var + eps), the running statistics and num_batches_tracked, so no
+  // "finalize" launch follows the convolution.  bn_mi == null: the partial rows are all there is (mmi_conv_fwd).
+  StatFold bn_fold;
+  float* bn_mi;
+  float* bn_rmean;
+  float* bn_rvar;
+  int64_t* bn_nbt;
+  int bn_nnbt;
+  float bn_eps, bn_momentum;
+  double bn_inv_rows, bn_unbias;  // 1 / rows, rows / (rows - 1)
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
   __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
   __shared__ int sk_last;
+  __shared__ int bn_flag;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -786,7 +798,30 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
       for (int idx = t; idx < 2 * BN; idx += 256) {
         const int s = idx / BN, c = idx - s * BN;
         const int col = n0 + c;
-        if (col < p.Ncol) p.stat_part[((int64_t)mt * 2 + s) * p.Ncol + col] = smem[(s * 2 + 0) * BN + c] + smem[(s * 2 + 1) * BN + c];
+        if (col < p.Ncol) st_agent(p.stat_part + ((int64_t)mt * 2 + s) * p.Ncol + col, smem[(s * 2 + 0) * BN + c] + smem[(s * 2 + 1) * BN + c]);
+      }
+      if constexpr (!DGRAD) {
+        if (p.bn_mi != nullptr) {  // uniform
+          __syncthreads();         // smem[0, 4*BN) has been consumed; the fold reuses it
+          double s1, s2;
+          if (stat_arrive<BN>(p.bn_fold, mt, nt, n0, reinterpret_cast<double*>(smem), &bn_flag, s1, s2)) {
+            const int col = n0 + t;
+            if (t < BN && col < p.Ncol) {
+              // as mmi_bn_finalize, except that the reciprocals come from the host and the square root is taken in fp32
+              // (fp64 division / sqrt are long software sequences whose registers this kernel cannot spare)
+              const double mean = s1 * p.bn_inv_rows;
+              double var = s2 * p.bn_inv_rows - mean * mean;  // biased (normalisation) variance
+              if (var < 0.0) var = 0.0;
+              p.bn_mi[col] = (float)mean;
+              p.bn_mi[p.Ncol + col] = 1.0f / sqrtf((float)(var + (double)p.bn_eps));
+              if (p.bn_rmean != nullptr) {
+                p.bn_rmean[col] = (float)((1.0 - p.bn_momentum) * (double)p.bn_rmean[col] + p.bn_momentum * mean);
+                p.bn_rvar[col] = (float)((1.0 - p.bn_momentum) * (double)p.bn_rvar[col] + p.bn_momentum * (var * p.bn_unbias));
+              }
+            }
+            if (nt == 0 && t < p.bn_nnbt) p.bn_nbt[t] += 1;
+          }
+        }
       }
       if (SK) __syncthreads();  // the next segment's prologue overwrites smem
     }
@@ -805,6 +840,11 @@ struct WgradP {
   int Mpix, Cout, Cin, KH, KW, Ho, Wo, H, W, stride, pad, ldx, ldy, Ntot, chunk, mtiles, ntiles, splits;
   int64_t slab_stride;
   uint32_t x_bytes;  // TAB loaders: byte extent of x including the margin in front of it
+  // split-K fold inside the launch: per-tile arrival counters (zero before and after); the workgroup that completes a
+  // tile's last split sums the splits' partial tiles in split order (deterministic) into DW (and DB): no reduce launch
+  int* cnt;
+  float* DW;
+  float* DB;
 };
 
 // LDS stages of the wgrad kernel: single-buffered (3+ workgroups per CU, +3..10 % measured on the 3x3 layers) except for
@@ -836,6 +876,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   __shared__ __align__(16) float smem[MMI_WGRAD_STAGES * STAGE];
   __shared__ uint2 ptab[TAB ? 2 : 1][TAB ? BK : 1];  // TAB: {source offset, invalid-tap mask} per pixel row, two slabs
+  __shared__ int fold_flag;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -1147,6 +1188,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     __syncthreads();
   }
 
+  const bool fold = p.cnt != nullptr;  // uniform
   if (want_bias) {  // fold the RPA row-lanes of each channel quad through LDS (free after the loop's last barrier)
     float* red = smem;  // [RPA][BM]
     *reinterpret_cast<f32x4*>(red + akr * BM + (t % VA) * 4) = bsum;
@@ -1155,7 +1197,9 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < RPA; ++i) s += red[i * BM + t];
-      p.OUTB[(int64_t)split * p.slab_stride + m0 + t] = s;
+      float* dst = p.OUTB + (int64_t)split * p.slab_stride + m0 + t;
+      if (fold) st_agent(dst, s);
+      else *dst = s;
     }
   }
   float* out = p.OUT + (int64_t)split * p.slab_stride;
@@ -1168,9 +1212,54 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < p.Cout) out[(int64_t)row * p.Ntot + col] = acc[i][j][r];
+          if (row < p.Cout) {
+            if (fold) st_agent(out + (int64_t)row * p.Ntot + col, acc[i][j][r]);
+            else out[(int64_t)row * p.Ntot + col] = acc[i][j][r];
+          }
         }
     }
+  }
+  if (!fold) return;
+  // ---- the last split of this tile to finish folds all of them, in split order ----
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's (write-through) stores have completed
+  __syncthreads();
+  if (t == 0) {
+    const int last = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.splits - 1;
+    if (last) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fold_flag = last;
+  }
+  __syncthreads();
+  if (!fold_flag) return;
+  // one 32x32 sub-tile at a time (16 values per lane): the splits' loads of a sub-tile are independent of each other
+#pragma unroll 1
+  for (int ij = 0; ij < TM * TN; ++ij) {
+    const int i = ij / TN, j = ij - i * TN;
+    const int col = n0 + wn * WN + j * 32 + l31;
+    const int rbase = m0 + wm * WM + i * 32 + 4 * lh;
+    if (col >= p.Ntot) continue;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+    const int64_t e0 = (int64_t)rbase * p.Ntot + col;
+#pragma unroll 1
+    for (int z = 0; z < p.splits; ++z) {
+      const float* part = p.OUT + (int64_t)z * p.slab_stride + e0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (rbase + dr < p.Cout) v[r] += ld_agent(part + (int64_t)dr * p.Ntot);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (rbase + dr < p.Cout) p.DW[e0 + (int64_t)dr * p.Ntot] = v[r];
+    }
+  }
+  if (want_bias && t < BM && m0 + t < p.Cout) {
+    float s = 0.f;
+    for (int z = 0; z < p.splits; ++z) s += ld_agent(p.OUTB + (int64_t)z * p.slab_stride + m0 + t);
+    p.DB[m0 + t] = s;
   }
 }
 
@@ -1317,12 +1406,28 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
   return f;
 }
 
-size_t sk_workspace_bytes(const FwdPlan& f) {
-  return f.sk_grid > 0 ? SK_COUNTER_BYTES + (size_t)f.sk_grid * 2 * f.bm * f.bn * sizeof(float) : 0;
+// Workspace of a forward / dgrad launch (zero-filled when first handed over, self-cleaning afterwards):
+//   [0, SK_COUNTER_BYTES)            stream-K arrival counters
+//   [.., + BN_COUNTER_BYTES)         arrival counters of the in-launch BatchNorm statistics fold (forward)
+//   [WS_HEADER_BYTES, ..)            no zero-fill needed: level-1 statistics partials (forward), then the stream-K slots
+// The header is the same for every shape and direction, because launches on one stream share one buffer.
+constexpr size_t BN_COUNTER_BYTES = (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int);
+constexpr size_t WS_HEADER_BYTES = SK_COUNTER_BYTES + BN_COUNTER_BYTES;
+size_t bn_l1_bytes(const FwdPlan& f, int Ncol) {
+  const int G = stat_group_size(f.mtiles);
+  return (((size_t)cdiv(f.mtiles, G) * 2 * Ncol * sizeof(float)) + 15) & ~(size_t)15;
 }
+bool bn_fold_fits(const FwdPlan& f) {
+  const int ngroups = cdiv(f.mtiles, stat_group_size(f.mtiles));
+  return (int64_t)ngroups * f.ntiles + f.ntiles <= MMI_STAT_MAX_COUNTERS;
+}
+size_t sk_slot_bytes(const FwdPlan& f) { return f.sk_grid > 0 ? (size_t)f.sk_grid * 2 * f.bm * f.bn * sizeof(float) : 0; }
+size_t sk_workspace_bytes(const FwdPlan& f) { return f.sk_grid > 0 ? WS_HEADER_BYTES + sk_slot_bytes(f) : 0; }
+size_t fwd_workspace_bytes(const FwdPlan& f, int Ncol) { return WS_HEADER_BYTES + bn_l1_bytes(f, Ncol) + sk_slot_bytes(f); }
 
 template <bool DGRAD, bool EPI = false>
-int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s) {
+int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s,
+                 size_t slot_offset = WS_HEADER_BYTES) {
   const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
   IgemmP p = p0;
   p.zero = zero_src();
@@ -1348,13 +1453,13 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     }
   }
   if (f.sk_grid > 0) {
-    if (workspace == nullptr || workspace_bytes < sk_workspace_bytes(f) || ((uintptr_t)workspace & 15)) {
+    if (workspace == nullptr || workspace_bytes < slot_offset + sk_slot_bytes(f) || ((uintptr_t)workspace & 15)) {
       mmi_set_error("%s: this shape runs the stream-K schedule and needs a 16-byte aligned workspace of %zu bytes (got %zu)",
-                    who, sk_workspace_bytes(f), workspace_bytes);
+                    who, slot_offset + sk_slot_bytes(f), workspace_bytes);
       return MMI_ERR_WORKSPACE;
     }
     p.sk_count = (int*)workspace;
-    p.sk_slots = (float*)((char*)workspace + SK_COUNTER_BYTES);
+    p.sk_slots = (float*)((char*)workspace + slot_offset);
     const dim3 grid(f.sk_grid), block(256);
     if (g_gemm_prec == 1) {
       if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
@@ -1483,7 +1588,7 @@ extern "C" int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d) {
 
 extern "C" size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_fwd_workspace") != MMI_OK || mmi_smallconv_supported(d)) return 0;
-  return sk_workspace_bytes(fwd_plan(d));
+  return fwd_workspace_bytes(fwd_plan(d), d->Cout);
 }
 
 extern "C" size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d) {
@@ -1494,14 +1599,23 @@ extern "C" size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d) {
 namespace {
 int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, int ldr, int act, float* y,
                   float* stat_partials, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream,
-                  const char* who) {
+                  const char* who, const mmi_bn_stats* bn = nullptr) {
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(x && w && y, "%s: null pointer", who);
   MMI_CHECK_ARG(!(bias && stat_partials), "%s: bias and BN statistics are mutually exclusive", who);
   const bool plain = residual == nullptr && act == MMI_ACT_NONE;
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   if (mmi_smallconv_supported(d) && plain) {
     MMI_CHECK_ARG(d->Cin != 24 || ((uintptr_t)x & 15) == 0, "%s: operands must be 16-byte aligned", who);
-    return mmi_smallconv_fwd(x, w, bias, y, stat_partials, d, (hipStream_t)stream);
+    if (int e = mmi_smallconv_fwd(x, w, bias, y, stat_partials, d, (hipStream_t)stream)) return e;
+    if (bn == nullptr) return MMI_OK;   // the CEM's direct convolutions keep the separate fold
+    if (int e = mmi_bn_finalize(stat_partials, mmi_smallconv_blocks(d), rows, d->Cout, bn->eps, bn->momentum, bn->running_mean,
+                                bn->running_var, bn->num_batches_tracked, bn->mean_invstd, stream)) return e;
+    if (bn->num_batches_tracked2 != nullptr) {
+      mmi_set_error("%s: two num_batches_tracked counters are not supported on this path", who);
+      return MMI_ERR_ARG;
+    }
+    return MMI_OK;
   }
   const bool vec = fwd_vec(d);
   MMI_CHECK_ARG(!vec || (((uintptr_t)x | (uintptr_t)w) & 15) == 0, "%s: operands must be 16-byte aligned", who);
@@ -1511,9 +1625,47 @@ int conv_fwd_impl(const float* x, const float* w, const float* bias, const float
   p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
-  return launch_igemm<false>(p, fwd_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+  const FwdPlan f = fwd_plan(d);
+  const bool fold = bn != nullptr && bn_fold_fits(f) &&
+                    (bn->num_batches_tracked2 == nullptr || bn->num_batches_tracked2 == bn->num_batches_tracked + 1);
+  if (fold) {
+    MMI_CHECK_ARG(stat_partials && bn->mean_invstd, "%s: BN statistics need the partials buffer and mean_invstd", who);
+    MMI_CHECK_ARG((bn->running_mean == nullptr) == (bn->running_var == nullptr), "%s: running stats must come in pairs", who);
+    if (workspace == nullptr || workspace_bytes < fwd_workspace_bytes(f, d->Cout) || ((uintptr_t)workspace & 15)) {
+      mmi_set_error("%s: needs a 16-byte aligned zero-initialised workspace of %zu bytes (got %zu)", who, fwd_workspace_bytes(f, d->Cout),
+                    workspace_bytes);
+      return MMI_ERR_WORKSPACE;
+    }
+    const int G = stat_group_size(f.mtiles);
+    p.bn_fold = StatFold{stat_partials, (float*)((char*)workspace + WS_HEADER_BYTES), (int*)((char*)workspace + SK_COUNTER_BYTES),
+                         f.mtiles, d->Cout, f.ntiles, G};
+    p.bn_mi = bn->mean_invstd;
+    p.bn_rmean = bn->running_mean; p.bn_rvar = bn->running_var;
+    p.bn_nbt = bn->num_batches_tracked;
+    p.bn_nnbt = bn->num_batches_tracked == nullptr ? 0 : (bn->num_batches_tracked2 != nullptr ? 2 : 1);
+    p.bn_eps = bn->eps; p.bn_momentum = bn->momentum;
+    p.bn_inv_rows = 1.0 / (double)rows; p.bn_unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  }
+  if (int e = launch_igemm<false>(p, f, vec, workspace, workspace_bytes, (hipStream_t)stream, WS_HEADER_BYTES + bn_l1_bytes(f, d->Cout)))
+    return e;
+  if (bn != nullptr && !fold) {  // (a list too long for the counter block, or counters that are not adjacent: separate fold)
+    if (int e = mmi_bn_finalize(stat_partials, f.mtiles, rows, d->Cout, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
+                                bn->num_batches_tracked, bn->mean_invstd, stream)) return e;
+    if (bn->num_batches_tracked2 != nullptr) {
+      mmi_set_error("%s: two num_batches_tracked counters must be adjacent int64 words", who);
+      return MMI_ERR_ARG;
+    }
+  }
+  return MMI_OK;
 }
 }  // namespace
+
+extern "C" int mmi_conv_bn_fwd(const float* x, const float* w, float* y, float* stat_partials, const mmi_bn_stats* bn,
+                               void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  MMI_CHECK_ARG(bn != nullptr && stat_partials != nullptr, "mmi_conv_bn_fwd: null BN arguments");
+  return conv_fwd_impl(x, w, nullptr, nullptr, 0, MMI_ACT_NONE, y, stat_partials, workspace, workspace_bytes, d, stream,
+                       "mmi_conv_bn_fwd", bn);
+}
 
 namespace {
 int fill_epilogue(IgemmP& p, const mmi_conv_desc* d, const mmi_linear_epilogue* e, bool dgrad, const float* out, const char* who) {
@@ -1678,12 +1830,17 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
 }
 }  // namespace
 
+// Workspace of a wgrad launch: [0, WG_COUNTER_BYTES) per-tile arrival counters of the in-launch split-K fold (zero-filled
+// when first handed over, self-cleaning afterwards), then the splits' partial slabs (no zero-fill needed).
+constexpr int WG_MAX_TILES = 4096;
+constexpr size_t WG_COUNTER_BYTES = (size_t)WG_MAX_TILES * sizeof(int);
 extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
   if (check_desc(d, "mmi_conv_wgrad_workspace") != MMI_OK) return 0;
   const WgPlan g = wgrad_plan(d);
   const size_t generic = g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
   const size_t small = mmi_smallconv_supported(d) ? mmi_smallconv_wgrad_workspace(d) : 0;
-  return generic > small ? generic : small;
+  const size_t body = generic > small ? generic : small;
+  return body ? WG_COUNTER_BYTES + body : 0;
 }
 
 extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
@@ -1691,23 +1848,30 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
   if (mmi_smallconv_supported(d) && dbias == nullptr) {
-    if (workspace == nullptr || workspace_bytes < mmi_smallconv_wgrad_workspace(d)) {
-      mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, mmi_smallconv_wgrad_workspace(d));
+    if (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d)) {
+      mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d));
       return MMI_ERR_WORKSPACE;
     }
-    return mmi_smallconv_wgrad(dy, x, dw, workspace, d, (hipStream_t)stream);
+    return mmi_smallconv_wgrad(dy, x, dw, (char*)workspace + WG_COUNTER_BYTES, d, (hipStream_t)stream);   // (never the counter block)
   }
   const WgPlan g = wgrad_plan(d);
   MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
   const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;
   const int64_t slab = wsize + d->Cout;  // weight gradient + bias-gradient tail
-  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.splits * slab * sizeof(float))) {
-    mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)g.splits * slab * sizeof(float));
+  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + (size_t)g.splits * slab * sizeof(float) ||
+                       ((uintptr_t)workspace & 15))) {
+    mmi_set_error("mmi_conv_wgrad: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
+                  WG_COUNTER_BYTES + (size_t)g.splits * slab * sizeof(float));
     return MMI_ERR_WORKSPACE;
   }
+  float* slabs = g.splits > 1 ? (float*)((char*)workspace + WG_COUNTER_BYTES) : nullptr;
+  static const bool fold_off = getenv("MMIDET_WGRAD_FOLD") != nullptr && atoi(getenv("MMIDET_WGRAD_FOLD")) == 0;  // (A/B switch)
+  const bool fold = g.splits > 1 && g.mtiles * g.ntiles <= WG_MAX_TILES && !fold_off;
   WgradP p{};
-  p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? (float*)workspace : dw;
-  p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? (float*)workspace + wsize : dbias);
+  p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? slabs : dw;
+  p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? slabs + wsize : dbias);
+  p.cnt = fold ? (int*)workspace : nullptr;
+  p.DW = dw; p.DB = dbias;
   p.zero = zero_src();
   if (p.zero == nullptr) {
     mmi_set_error("mmi_conv_wgrad: cannot resolve the zero-source symbol");
@@ -1757,10 +1921,10 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   else LAUNCHW(64, 64, true);
 #undef LAUNCHW
   MMI_CHECK_LAUNCH("mmi_conv_wgrad");
-  if (g.splits > 1) {
+  if (g.splits > 1 && !fold) {
     // without dbias only the weight part [0, wsize) of every slab is reduced
     const int64_t count = dbias != nullptr ? slab : wsize;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, s, (const float*)workspace, dw, dbias, wsize, slab, count,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, s, (const float*)slabs, dw, dbias, wsize, slab, count,
                        g.splits);
     MMI_CHECK_LAUNCH("mmi_conv_wgrad(reduce)");
   }

@@ -24,7 +24,10 @@ struct LossP {
   const float* anch;       // (nl,cap,2)
   const int* counts;       // (nl)
   float* iou;              // (nl,cap) scratch
-  double* acc;             // (nl,3): sum(1-iou), sum cls bce, sum obj bce
+  double* acc;             // (nl, ACC_STRIDE) per-workgroup partial sums: [0,64) sum(1-iou), [64,128) sum cls bce, [128,..) sum obj bce
+  int* cnt[MAXL];          // per-cell number of records
+  int* cellid;             // (nl,cap) cell of every record
+  float* grec;             // (nl,cap,no) gradient contribution of every record (slot 4 unused)
   int nl, na, no, nc, cap, bs;
   float hbox, hobj, hcls, gr, cp, cn;
 };
@@ -102,7 +105,11 @@ __device__ __forceinline__ float bce_logits(float x, float t) {  // nn.BCEWithLo
   return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
 }
 
-__device__ __forceinline__ void block_add(double v, double* dst, double* sh) {
+constexpr int REC_BLOCKS = 64, OBJ_BLOCKS = 1024, ACC_STRIDE = 2 * REC_BLOCKS + OBJ_BLOCKS;
+
+// workgroup sum -> its own slot (no atomics: loss_finalize_kernel adds the slots in a fixed order, so the loss value is
+// run-to-run bit-identical)
+__device__ __forceinline__ void block_sum_to(double v, double* dst, double* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -112,7 +119,7 @@ __device__ __forceinline__ void block_add(double v, double* dst, double* sh) {
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
-    if (s != 0.0) atomicAdd(dst, s);
+    *dst = s;
   }
 }
 
@@ -128,7 +135,6 @@ __global__ __launch_bounds__(256) void loss_records_kernel(LossP P) {
     const int b = (int)ix[r], a = (int)ix[P.cap + r], gj = (int)ix[2 * (int64_t)P.cap + r], gi = (int)ix[3 * (int64_t)P.cap + r];
     const int64_t cell = (((int64_t)b * P.na + a) * P.ny[l] + gj) * P.nx[l] + gi;
     const float* ps = P.p[l] + cell * no;
-    float* dps = P.dp[l] + cell * no;
     const float* an = P.anch + ((int64_t)l * P.cap + r) * 2;
     const float s0 = sigm(ps[0]), s1 = sigm(ps[1]), s2 = sigm(ps[2]), s3 = sigm(ps[3]);
     const float px = s0 * 2.f - 0.5f, py = s1 * 2.f - 0.5f;                 // loss.py:128
@@ -137,23 +143,57 @@ __global__ __launch_bounds__(256) void loss_records_kernel(LossP P) {
     P.iou[(int64_t)l * P.cap + r] = c.v;
     s_box += (double)(1.0f - c.v);                                           // loss.py:132
     atomicMax(P.owner[l] + cell, r);                                         // last record wins (loss.py:135)
+    atomicAdd(P.cnt[l] + cell, 1);                                           // (integer: order-independent)
+    P.cellid[(int64_t)l * P.cap + r] = (int)cell;
+    // Several records may land in one cell (two targets whose boxes fall into the same grid cell under the same anchor):
+    // their gradients are summed by loss_scatter_kernel in record order, not with float atomics.
+    float* grow = P.grec + ((int64_t)l * P.cap + r) * no;
     const float gb = -(float)P.bs * P.hbox / (float)n;                       // d total / d iou
-    atomicAdd(dps + 0, gb * c.d[0] * 2.f * s0 * (1.f - s0));
-    atomicAdd(dps + 1, gb * c.d[1] * 2.f * s1 * (1.f - s1));
-    atomicAdd(dps + 2, gb * c.d[2] * 8.f * s2 * s2 * (1.f - s2) * an[0]);
-    atomicAdd(dps + 3, gb * c.d[3] * 8.f * s3 * s3 * (1.f - s3) * an[1]);
+    grow[0] = gb * c.d[0] * 2.f * s0 * (1.f - s0);
+    grow[1] = gb * c.d[1] * 2.f * s1 * (1.f - s1);
+    grow[2] = gb * c.d[2] * 8.f * s2 * s2 * (1.f - s2) * an[0];
+    grow[3] = gb * c.d[3] * 8.f * s3 * s3 * (1.f - s3) * an[1];
     if (P.nc > 1) {                                                          // loss.py:138-141
       const int tc = (int)P.tcls[(int64_t)l * P.cap + r];
       const float gc = (float)P.bs * P.hcls / ((float)n * (float)P.nc);
       for (int k = 0; k < P.nc; ++k) {
         const float x = ps[5 + k], t = (k == tc) ? P.cp : P.cn;
         s_cls += (double)bce_logits(x, t);
-        atomicAdd(dps + 5 + k, gc * (sigm(x) - t));
+        grow[5 + k] = gc * (sigm(x) - t);
       }
+    } else {
+      for (int k = 0; k < P.nc; ++k) grow[5 + k] = 0.f;
     }
   }
-  block_add(s_box, P.acc + l * 3 + 0, sh);
-  block_add(s_cls, P.acc + l * 3 + 1, sh);
+  block_sum_to(s_box, P.acc + (int64_t)l * ACC_STRIDE + blockIdx.x, sh);
+  block_sum_to(s_cls, P.acc + (int64_t)l * ACC_STRIDE + REC_BLOCKS + blockIdx.x, sh);
+}
+
+// grid (record blocks, nl): the LAST record of a cell (its owner) writes the cell's box/class gradient = the sum over the
+// cell's records in increasing record order (one term for nearly every cell)
+__global__ __launch_bounds__(256) void loss_scatter_kernel(LossP P) {
+  const int l = blockIdx.y;
+  const int n = P.counts[l];
+  const int no = P.no;
+  const int* cid = P.cellid + (int64_t)l * P.cap;
+  const float* g = P.grec + (int64_t)l * P.cap * no;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    const int cell = cid[r];
+    if (P.owner[l][cell] != r) continue;
+    float* dps = P.dp[l] + (int64_t)cell * no;
+    if (P.cnt[l][cell] == 1) {
+      for (int k = 0; k < no; ++k)
+        if (k != 4) dps[k] = g[(int64_t)r * no + k];
+      continue;
+    }
+    for (int k = 0; k < no; ++k) {
+      if (k == 4) continue;
+      float s = 0.f;
+      for (int q = 0; q <= r; ++q)
+        if (cid[q] == cell) s += g[(int64_t)q * no + k];
+      dps[k] = s;
+    }
+  }
 }
 
 // grid (cell blocks, nl): objectness BCE over every cell, writes dp[...,4]
@@ -172,7 +212,7 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossP P) {
     s += (double)bce_logits(x, t);
     P.dp[l][c * no + 4] = g * (sigm(x) - t);
   }
-  block_add(s, P.acc + l * 3 + 2, sh);
+  block_sum_to(s, P.acc + (int64_t)l * ACC_STRIDE + 2 * REC_BLOCKS + blockIdx.x, sh);
 }
 
 // out[0] = loss (scaled by bs), out[1..4] = lbox, lobj, lcls, Detectloss (loss.py:154-184)
@@ -182,11 +222,15 @@ __global__ void loss_finalize_kernel(LossP P, const float* __restrict__ combine,
   float lbox = 0.f, lobj = 0.f, lcls = 0.f;
   for (int l = 0; l < P.nl; ++l) {
     const int n = P.counts[l];
+    const double* a = P.acc + (int64_t)l * ACC_STRIDE;
+    double sb = 0.0, sc = 0.0, so = 0.0;          // fixed-order sums of the per-workgroup slots (unused slots hold zero)
+    for (int i = 0; i < REC_BLOCKS; ++i) sb += a[i], sc += a[REC_BLOCKS + i];
+    for (int i = 0; i < OBJ_BLOCKS; ++i) so += a[2 * REC_BLOCKS + i];
     if (n > 0) {
-      lbox += (float)(P.acc[l * 3 + 0] / (double)n);
-      if (P.nc > 1) lcls += (float)(P.acc[l * 3 + 1] / ((double)n * P.nc));
+      lbox += (float)(sb / (double)n);
+      if (P.nc > 1) lcls += (float)(sc / ((double)n * P.nc));
     }
-    lobj += (float)(P.acc[l * 3 + 2] / (double)P.cells[l]) * P.balance[l];
+    lobj += (float)(so / (double)P.cells[l]) * P.balance[l];
   }
   lbox *= P.hbox;
   lobj *= P.hobj;
@@ -211,9 +255,13 @@ __global__ void loss_finalize_kernel(LossP P, const float* __restrict__ combine,
 
 }  // namespace
 
+// acc (nl*ACC_STRIDE doubles) | iou (nl*cap floats) | cellid (nl*cap ints) | grec (nl*cap*MAX_NO floats) | owner, cnt
+// (total_cells ints each).  The entry point does not know nc here, so grec is sized for MAX_NO outputs per anchor.
+constexpr int MAX_NO = 96;
 extern "C" size_t mmi_detect_loss_workspace(int nl, int64_t total_cells, int64_t cap) {
-  // acc (nl*3 doubles) | iou (nl*cap floats) | owner (total_cells ints)
-  return ((size_t)nl * 3 * sizeof(double) + (size_t)nl * (cap > 0 ? cap : 1) * sizeof(float) + (size_t)total_cells * sizeof(int) + 15) & ~(size_t)15;
+  const size_t c = (size_t)(cap > 0 ? cap : 1);
+  return ((size_t)nl * ACC_STRIDE * sizeof(double) + (size_t)nl * c * (sizeof(float) + sizeof(int) + MAX_NO * sizeof(float)) +
+          2 * (size_t)total_cells * sizeof(int) + 15) & ~(size_t)15;
 }
 
 extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, const int32_t* grids_host, int nl, int bs,
@@ -222,7 +270,7 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
                                float hcls, float gr, float cp, float cn, const float* combine, int ncombine, float alpha,
                                int flag, void* workspace, size_t workspace_bytes, float* out5, void* stream) {
   MMI_CHECK_ARG(preds && dpreds && grids_host && balance_host && counts && workspace && out5, "mmi_detect_loss: null pointer");
-  MMI_CHECK_ARG(nl > 0 && nl <= MAXL && bs > 0 && na > 0 && nc > 0 && cap >= 0 && cap < (1LL << 30), "mmi_detect_loss: bad sizes");
+  MMI_CHECK_ARG(nl > 0 && nl <= MAXL && bs > 0 && na > 0 && nc > 0 && nc + 5 <= MAX_NO && cap >= 0 && cap < (1LL << 30), "mmi_detect_loss: bad sizes");
   MMI_CHECK_ARG(cap == 0 || (idx && tcls && tbox && anch), "mmi_detect_loss: null target arrays");
   LossP P{};
   int64_t total = 0;
@@ -235,13 +283,20 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
   MMI_CHECK_ARG(workspace_bytes >= mmi_detect_loss_workspace(nl, total, cap), "mmi_detect_loss: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)workspace;
+  const size_t capn = (size_t)(cap > 0 ? cap : 1);
   P.acc = (double*)w;
-  w += (size_t)nl * 3 * sizeof(double);
+  w += (size_t)nl * ACC_STRIDE * sizeof(double);
   P.iou = (float*)w;
-  w += (size_t)nl * (cap > 0 ? cap : 1) * sizeof(float);
+  w += (size_t)nl * capn * sizeof(float);
+  P.cellid = (int*)w;
+  w += (size_t)nl * capn * sizeof(int);
+  P.grec = (float*)w;
+  w += (size_t)nl * capn * MAX_NO * sizeof(float);
   int* owner = (int*)w;
-  if (hipMemsetAsync(P.acc, 0, (size_t)nl * 3 * sizeof(double), s) != hipSuccess ||
-      hipMemsetAsync(owner, 0xFF, (size_t)total * sizeof(int), s) != hipSuccess) {
+  int* cnt = owner + total;
+  if (hipMemsetAsync(P.acc, 0, (size_t)nl * ACC_STRIDE * sizeof(double), s) != hipSuccess ||
+      hipMemsetAsync(owner, 0xFF, (size_t)total * sizeof(int), s) != hipSuccess ||
+      hipMemsetAsync(cnt, 0, (size_t)total * sizeof(int), s) != hipSuccess) {
     mmi_set_error("mmi_detect_loss: memset failed");
     return MMI_ERR_LAUNCH;
   }
@@ -250,6 +305,7 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
     P.p[l] = preds[l];
     P.dp[l] = dpreds[l];
     P.owner[l] = owner + off;
+    P.cnt[l] = cnt + off;
     off += P.cells[l];
     P.balance[l] = balance_host[l];
     if (P.cells[l] > maxcells) maxcells = P.cells[l];
@@ -262,11 +318,14 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
   P.nl = nl; P.na = na; P.no = nc + 5; P.nc = nc; P.cap = (int)cap; P.bs = bs;
   P.hbox = hbox; P.hobj = hobj; P.hcls = hcls; P.gr = gr; P.cp = cp; P.cn = cn;
   if (cap > 0) {
-    hipLaunchKernelGGL(loss_records_kernel, dim3(cdiv(cap, 256) > 64 ? 64 : cdiv(cap, 256), nl), dim3(256), 0, s, P);
+    const dim3 rgrid(cdiv(cap, 256) > REC_BLOCKS ? REC_BLOCKS : cdiv(cap, 256), nl);
+    hipLaunchKernelGGL(loss_records_kernel, rgrid, dim3(256), 0, s, P);
     MMI_CHECK_LAUNCH("mmi_detect_loss(records)");
+    hipLaunchKernelGGL(loss_scatter_kernel, rgrid, dim3(256), 0, s, P);
+    MMI_CHECK_LAUNCH("mmi_detect_loss(scatter)");
   }
   int ob = cdiv(maxcells, 256);
-  if (ob > 1024) ob = 1024;
+  if (ob > OBJ_BLOCKS) ob = OBJ_BLOCKS;
   hipLaunchKernelGGL(loss_obj_kernel, dim3(ob, nl), dim3(256), 0, s, P);
   MMI_CHECK_LAUNCH("mmi_detect_loss(obj)");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, P, combine, ncombine, alpha, flag, out5);

@@ -24,6 +24,12 @@ class ConvDesc(Structure):
                                        'ldy')]
 
 
+class BnStats(Structure):
+    """mmi_bn_stats (include/mmidet_hip.h)."""
+    _fields_ = [('eps', c_float), ('momentum', c_float), ('running_mean', c_void_p), ('running_var', c_void_p),
+                ('num_batches_tracked', c_void_p), ('num_batches_tracked2', c_void_p), ('mean_invstd', c_void_p)]
+
+
 class LinearEpilogue(Structure):
     """mmi_linear_epilogue (include/mmidet_hip.h)."""
     _fields_ = [('kind', c_int32), ('ldaux', c_int32), ('ldaux_out', c_int32), ('p_drop', c_float), ('aux', c_void_p),
@@ -43,6 +49,11 @@ _SIGS = {
     'mmi_set_uniform_loaders': (c_int, [c_int]),
     'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_fwd': (c_int, [P, P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_bn_fwd': (c_int, [P, P, P, P, POINTER(BnStats), P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_bn_act_fwd_split': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int64, c_int, c_int, P]),
+    'mmi_bn_act_bwd_workspace': (c_size_t, [c_int64, c_int]),
+    'mmi_bn_act_bwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P, P, c_size_t, P, c_int, P, P, P, P, c_int64, c_int,
+                               c_int, c_int, P]),
     'mmi_conv_bias_act_fwd': (c_int, [P, P, P, P, c_int, c_int, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_detect_decode': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_float, P, P]),
     'mmi_nms_workspace': (c_size_t, [c_int, c_int64, c_int, c_int]),

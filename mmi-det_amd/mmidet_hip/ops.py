@@ -34,12 +34,15 @@ def scratch(nfloats, device, slot=0, stream=None):
 _zeroed = {}
 
 
-def zeroed_scratch(nbytes, device, stream=None):
-    """Grow-only, zero-filled-at-birth byte workspace per (device, stream) for the stream-K convolutions: the kernels keep
-    their arrival counters at zero between launches, so the fill happens once per buffer (include/mmidet_hip.h)."""
-    key = (device, _stream() if stream is None else stream)
+def zeroed_scratch(nbytes, device, stream=None, tag=0):
+    """Grow-only, zero-filled-at-birth byte workspace per (device, tag, stream): the kernels keep the arrival counters at its
+    head at zero between launches, so the fill happens once per buffer (include/mmidet_hip.h).  One tag per workspace layout
+    (0: conv forward / dgrad, 'w': wgrad, 'bn': BatchNorm backward) -- what is a counter in one layout is scratch in another."""
+    key = (device, tag, _stream() if stream is None else stream)
     buf = _zeroed.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and stream is not None and stream != _stream():
+            _retired.append(buf)        # (see scratch(): a side stream may still be using it)
         buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         _zeroed[key] = buf
     return buf
@@ -156,7 +159,7 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     nbytes = lib.conv_wgrad_workspace(d)
     if overlap:
         main, side = torch.cuda.current_stream(), _side_stream(w.device)
-        ws = scratch(nbytes // 4, w.device, slot=4, stream=side.cuda_stream) if nbytes else None
+        ws = zeroed_scratch(nbytes, w.device, side.cuda_stream, tag='w') if nbytes else None
         side.wait_stream(main)
         lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
                        d, side.cuda_stream)
@@ -164,7 +167,7 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
             _pending.append((dy, x))
             _pending_sides[side.cuda_stream] = side
     else:
-        ws = scratch(nbytes // 4, w.device, slot=1) if nbytes else None
+        ws = zeroed_scratch(nbytes, w.device, tag='w') if nbytes else None
         lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
                        d, _stream())
     return (dw, db) if want_bias else dw
@@ -198,71 +201,235 @@ def join_pending():
         _retired.clear()
 
 
+class Dest:
+    """A pre-allocated NHWC buffer that producers write channel slices of (C3's concat buffer: models/common.py:650 of the
+    reference without the copy).  Passed to the ops as (Dest, first channel): a plain Python object, invisible to autograd."""
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _dest_view(dest, shape):
+    holder, off = dest
+    out = holder.t[..., off:off + shape[-1]]
+    assert tuple(out.shape) == tuple(shape), 'destination slice %s does not fit the output %s' % (tuple(out.shape), tuple(shape))
+    return out
+
+
+def _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, nbt2, s):
+    """conv + BatchNorm statistics (training: folded inside the conv launch) -> mean_invstd (2*cout)."""
+    mi = torch.empty(2 * cout, dtype=x.dtype, device=x.device)
+    nb = lib.conv_fwd_workspace(d)
+    ws = zeroed_scratch(nb, x.device, s) if nb else None
+    if training:
+        nrb = lib.conv_fwd_row_blocks(d)
+        part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows (the CEM's separate fold)
+        bn = lib.BnStats(eps, momentum, rmean.data_ptr(), rvar.data_ptr(), nbt.data_ptr() if nbt is not None else None,
+                         nbt2.data_ptr() if nbt2 is not None else None, mi.data_ptr())
+        lib.conv_bn_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), part.data_ptr(), bn, ws.data_ptr() if nb else None, nb, d, s)
+    else:
+        lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, ws.data_ptr() if nb else None, nb, d, s)
+        lib.bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), cout, eps, mi.data_ptr(), s)
+    return mi
+
+
+def _dgrad_accumulate(dy, w, dx, d, dd, skip, s):
+    """dx = conv_transpose(dy, w) + skip.  1x1 stride-1 layers add in the GEMM epilogue (MMI_EPI_ACCUMULATE); others in a pass
+    of their own."""
+    skip, lds = rows_of(skip)
+    if d.KH == 1 and d.stride == 1 and d.Cin % 4 == 0 and d.Cout % 4 == 0 and dd.ldy % 4 == 0 and lds % 4 == 0:
+        nb = lib.conv_dgrad_workspace(dd)
+        ws = zeroed_scratch(nb, dy.device, s) if nb else None
+        e = lib.LinearEpilogue(lib.EPI_ACCUMULATE, lds, lds, 0.0, skip.data_ptr(), None, 0, None)
+        lib.linear_dgrad_fused(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, dd, e, s)
+    else:
+        conv_dgrad(dy, w, dx, dd, s)
+        lib.add(dx.data_ptr(), d.Cin, skip.data_ptr(), lds, dx.data_ptr(), d.Cin, _nrows(dx), d.Cin, s)
+
+
 class _ConvBnAct(Function):
-    """act(BN(conv(x))) [+ residual]; training-mode BN statistics come out of the conv epilogue."""
+    """act(BN(conv(x))) [+ residual]; training-mode BN statistics are finished inside the conv launch.
+    skip=True also returns x itself as a second output: a Bottleneck hands that to its second conv as the residual, so the
+    shortcut's gradient arrives here as a second incoming gradient and is added in the dgrad epilogue instead of by autograd's
+    fan-out accumulation (an ATen kernel).  dest=(Dest, channel): write the output into that slice of a wider buffer."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum):
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum, skip, dest):
+        x_in = x
         x, ldx = rows_of(x)
         w = _ohwi(w)
         cout, k = w.shape[0], w.shape[2]
         d = _desc(x.shape, cout, k, stride, ldx, cout)
         y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
         rows = d.N * d.Ho * d.Wo
-        mi = torch.empty(2 * cout, dtype=x.dtype, device=x.device)
         s = _stream()
-        if training:
-            nrb = lib.conv_fwd_row_blocks(d)
-            part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows
-            conv_fwd(x, w, None, y, part, d, s)
-            lib.bn_finalize(part.data_ptr(), nrb, rows, cout, eps, momentum, rmean.data_ptr(), rvar.data_ptr(),
-                            nbt.data_ptr() if nbt is not None else None, mi.data_ptr(), s)
-        else:
-            conv_fwd(x, w, None, y, None, d, s)
-            lib.bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), cout, eps, mi.data_ptr(), s)
-        out = torch.empty_like(y)
+        mi = _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, None, s)
+        out = _dest_view(dest, y.shape) if dest is not None else torch.empty_like(y)
+        ldo = rows_of(out)[1]
+        assert out.stride(-1) == 1 and rows_of(out)[0] is out, 'the destination slice must be a strided NHWC view'
         if residual is not None:
             residual, ldr = rows_of(residual)
         lib.bn_act_fwd(y.data_ptr(), cout, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                        residual.data_ptr() if residual is not None else None, ldr if residual is not None else 0,
-                       out.data_ptr(), cout, rows, cout, act, s)
+                       out.data_ptr(), ldo, rows, cout, act, s)
         ctx.save_for_backward(x, w, y, mi, gamma, beta)
-        ctx.cfg = (d, act, training, residual is not None)
-        return out
+        ctx.cfg = (d, act, training, residual is not None, skip)
+        return (out, x_in) if skip else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dskip=None):
         x, w, y, mi, gamma, beta = ctx.saved_tensors
-        d, act, training, has_res = ctx.cfg
+        d, act, training, has_res, skip = ctx.cfg
         dout, ldd = rows_of(dout)
         cout = d.Cout
         rows = d.N * d.Ho * d.Wo
         s = _stream()
-        nparts = lib.bn_bwd_parts(rows)
-        part = scratch(nparts * 2 * cout, x.device)
-        lib.bn_act_bwd_reduce(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                              part.data_ptr(), rows, cout, act, s)
+        nbw = lib.bn_act_bwd_workspace(rows, cout)
+        ws = zeroed_scratch(nbw, x.device, s, tag='bn')
         dy = torch.empty_like(y)
         dgamma = grad_like(gamma)
         dbeta = grad_like(beta)
-        lib.bn_act_bwd_apply(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                             part.data_ptr(), nparts, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), rows, cout,
-                             act, 0 if training else 1, s)
+        lib.bn_act_bwd(y.data_ptr(), cout, dout.data_ptr(), ldd, None, 0, cout, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                       ws.data_ptr(), nbw, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), None, None, rows, cout, act,
+                       0 if training else 1, s)
         dx = None
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
-            conv_dgrad(dy, w, dx, dd, s)
+            if skip and dskip is not None:
+                _dgrad_accumulate(dy, w, dx, d, dd, dskip, s)
+            else:
+                conv_dgrad(dy, w, dx, dd, s)
         if both:
             _join_side(x.device)
-        return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, w, gamma, beta, rmean, rvar, nbt, stride=1, act=ACT_SILU, residual=None, training=True, eps=1e-3,
-                momentum=0.03):
-    return _ConvBnAct.apply(x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum)
+                momentum=0.03, skip=False, dest=None):
+    return _ConvBnAct.apply(x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum, skip, dest)
+
+
+def back_to_back(*ts):
+    """Equally shaped dense tensors that lie one after the other in memory (pack_pair / fusion_ops.pack_qkv)."""
+    a = ts[0]
+    n = a.numel() * a.element_size()
+    return all(t.shape == a.shape and t.dtype == a.dtype and t.data_ptr() == a.data_ptr() + i * n for i, t in enumerate(ts))
+
+
+class _DualConvBnAct(Function):
+    """C3's cv1 and cv2 (models/common.py:645-650 of the reference: two 1x1 Conv modules over the same input) as ONE GEMM with
+    2*c_ output channels, one BatchNorm statistics pass and one normalise/activate pass, whose first half `a` feeds the
+    bottleneck chain and whose second half `b` is written straight into the buffer cv3 reads (no torch.cat copy).  Backward:
+    one BatchNorm backward over both halves (two incoming gradients), ONE input-gradient GEMM (no fan-out add), the two weight
+    gradients separately (each parameter keeps its own .grad).  The caller guarantees that the two layers' parameters and
+    buffers are back to back in memory (C3.packed())."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, g1, b1, g2, b2, rm1, rv1, nbt1, nbt2, act, training, eps, momentum, dest):
+        x, ldx = rows_of(x)
+        w1, w2 = _ohwi(w1), _ohwi(w2)
+        c_ = w1.shape[0]
+        cout = 2 * c_
+        d = _desc(x.shape, cout, 1, 1, ldx, cout)
+        y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+        rows = d.N * d.Ho * d.Wo
+        s = _stream()
+        mi = _bn_forward(x, w1, y, d, cout, rows, training, eps, momentum, rm1, rv1, nbt1, nbt2, s)
+        a = torch.empty((d.N, d.Ho, d.Wo, c_), dtype=x.dtype, device=x.device)
+        b = _dest_view(dest, a.shape)
+        ldb = rows_of(b)[1]
+        lib.bn_act_fwd_split(y.data_ptr(), cout, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(), None, 0, a.data_ptr(), c_,
+                             b.data_ptr(), ldb, c_, rows, cout, act, s)
+        ctx.save_for_backward(x, w1, w2, y, mi, g1, b1, g2, b2)
+        ctx.cfg = (d, act, training, c_)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        x, w1, w2, y, mi, g1, b1, g2, b2 = ctx.saved_tensors
+        d, act, training, c_ = ctx.cfg
+        cout, rows, s = 2 * c_, d.N * d.Ho * d.Wo, _stream()
+        da, lda = rows_of(da)
+        db, ldb = rows_of(db)
+        nbw = lib.bn_act_bwd_workspace(rows, cout)
+        ws = zeroed_scratch(nbw, x.device, s, tag='bn')
+        dy = torch.empty_like(y)
+        dg1, dbt1, dg2, dbt2 = grad_like(g1), grad_like(b1), grad_like(g2), grad_like(b2)
+        lib.bn_act_bwd(y.data_ptr(), cout, da.data_ptr(), lda, db.data_ptr(), ldb, c_, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                       ws.data_ptr(), nbw, dy.data_ptr(), cout, dg1.data_ptr(), dbt1.data_ptr(), dg2.data_ptr(), dbt2.data_ptr(),
+                       rows, cout, act, 0 if training else 1, s)
+        both = OVERLAP_WGRAD and ctx.needs_input_grad[0]
+        d1 = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, c_, 1, 1, 1, 0, d.ldx, cout)
+        dw1 = _wgrad(dy[..., :c_], cout, x, d.ldx, w1, d1, overlap=both) if ctx.needs_input_grad[1] else None
+        dw2 = _wgrad(dy[..., c_:], cout, x, d.ldx, w2, d1, overlap=both) if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
+            dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.Cin, cout)
+            conv_dgrad(dy, w1, dx, dd, s)
+        if both:
+            _join_side(x.device)
+        return dx, dw1, dw2, dg1, dbt1, dg2, dbt2, None, None, None, None, None, None, None, None, None
+
+
+def dual_conv_bn_act(x, w1, w2, g1, b1, g2, b2, rm1, rv1, nbt1, nbt2, act, training, eps, momentum, dest):
+    return _DualConvBnAct.apply(x, w1, w2, g1, b1, g2, b2, rm1, rv1, nbt1, nbt2, act, training, eps, momentum, dest)
+
+
+class _CatAlias(Function):
+    """The concat of two tensors that already ARE the two channel halves of one buffer: returns the buffer, copies nothing;
+    the gradient goes back as two channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, a, b, holder):
+        cat = holder.t
+        ca = a.shape[-1]
+        assert a.data_ptr() == cat.data_ptr() and b.data_ptr() == cat.data_ptr() + 4 * ca and ca + b.shape[-1] == cat.shape[-1], \
+            'cat_alias: the inputs are not the channel halves of the buffer'
+        ctx.ca = ca
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
+def cat_alias(a, b, holder):
+    return _CatAlias.apply(a, b, holder)
+
+
+def pack_pair(model):
+    """Re-seat cv1 / cv2 of every C3 (conv weights, BatchNorm weight / bias / running statistics / num_batches_tracked) on
+    shared buffers, cv1's part first: same Parameters, same state_dict keys and values, but the two 1x1 convolutions over the
+    same input now run as one GEMM (C3.forward checks the addresses on every call, so a model moved afterwards -- .to(), deep
+    copy -- just takes the two-convolution path again).  Call before anything caches parameter addresses (optimizer pointer
+    tables, gradient buckets).  Returns the number of C3 modules packed."""
+    n = 0
+    for m in model.modules():
+        if type(m).__name__ != 'C3' or not hasattr(m.cv1, 'bn') or not hasattr(m.cv2, 'bn'):
+            continue
+        w1, w2 = m.cv1.conv.weight, m.cv2.conv.weight
+        if w1.shape != w2.shape or w1.shape[2:] != (1, 1) or w1.grad is not None or w2.grad is not None:
+            continue
+        pairs = [(w1, w2)] + [(getattr(m.cv1.bn, k), getattr(m.cv2.bn, k))
+                              for k in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')]
+        for a, b in pairs:
+            if back_to_back(a.data, b.data) and a.is_contiguous(memory_format=torch.channels_last if a.dim() == 4 else torch.contiguous_format):
+                continue
+            flat = torch.cat([a.data.reshape(-1), b.data.reshape(-1)]) if a.dim() != 4 else \
+                torch.cat([a.data.permute(0, 2, 3, 1).reshape(-1), b.data.permute(0, 2, 3, 1).reshape(-1)])
+            k = a.numel()
+            for i, p in enumerate((a, b)):
+                piece = flat[i * k:(i + 1) * k]
+                if a.dim() == 4:      # (O,I,1,1) logical shape over OHWI memory
+                    p.data = piece.view(a.shape[0], a.shape[2], a.shape[3], a.shape[1]).permute(0, 3, 1, 2)
+                else:
+                    p.data = piece.view(a.shape)
+        n += 1
+    return n
 
 
 class _ConvBias(Function):

@@ -51,12 +51,13 @@ class Conv(nn.Module):
         assert isinstance(self.act, nn.Identity), 'unsupported activation %r' % self.act
         return ACT_NONE
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, skip=False, dest=None):
+        """skip=True: also return x as a second output (the Bottleneck shortcut, see ops._ConvBnAct); dest=(ops.Dest, channel):
+        write the output into that channel slice of a wider buffer."""
         w, b, rm, rv, nbt = _bn_args(self.bn)
         return ops.conv_bn_act(x, self.conv.weight, w, b, rm, rv, nbt, stride=self.conv.stride[0], act=self._act_id(),
                                residual=residual, training=self.bn.training, eps=self.bn.eps,
-                               momentum=self.bn.momentum)
-
+                               momentum=self.bn.momentum, skip=skip, dest=dest)
 
     def fuseforward(self, x, residual=None):
         """After Model.fuse() (models/common.py:124-125): the folded conv carries the bias, BN is gone."""
@@ -72,8 +73,14 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, 3, 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):  # the residual add rides in cv2's normalise/activate pass
-        return self.cv2(self.cv1(x), residual=x if self.add else None)
+    def forward(self, x, dest=None):
+        # the residual add rides in cv2's normalise/activate pass; its gradient in cv1's input-gradient GEMM
+        if hasattr(self.cv1, 'bn') and hasattr(self.cv2, 'bn'):
+            if self.add:
+                h, xs = self.cv1(x, skip=True)
+                return self.cv2(h, residual=xs, dest=dest)
+            return self.cv2(self.cv1(x), dest=dest)
+        return self.cv2(self.cv1(x), residual=x if self.add else None)        # after Model.fuse()
 
 
 class C3(nn.Module):
@@ -85,8 +92,41 @@ class C3(nn.Module):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
+    def packed(self):
+        """True when cv1 / cv2 share buffers (ops.pack_pair) and agree in everything the merged kernel assumes."""
+        a, b = self.cv1, self.cv2
+        if not (hasattr(a, 'bn') and hasattr(b, 'bn')):
+            return False
+        key = tuple(t.data_ptr() for t in (a.conv.weight, b.conv.weight, a.bn.weight, b.bn.weight, a.bn.bias, b.bn.bias,
+                                           a.bn.running_mean, b.bn.running_mean, a.bn.running_var, b.bn.running_var,
+                                           a.bn.num_batches_tracked, b.bn.num_batches_tracked))
+        if getattr(self, '_pack_key', None) != key:
+            ok = (a.conv.weight.is_cuda and a.conv.weight.shape[0] % 4 == 0 and a._act_id() == b._act_id()
+                  and a.bn.eps == b.bn.eps and a.bn.momentum == b.bn.momentum
+                  and a.conv.weight.is_contiguous(memory_format=torch.channels_last)
+                  and b.conv.weight.is_contiguous(memory_format=torch.channels_last)
+                  and all(ops.back_to_back(u, v) for u, v in (
+                      (a.conv.weight, b.conv.weight), (a.bn.weight, b.bn.weight), (a.bn.bias, b.bn.bias),
+                      (a.bn.running_mean, b.bn.running_mean), (a.bn.running_var, b.bn.running_var),
+                      (a.bn.num_batches_tracked, b.bn.num_batches_tracked))))
+            self._pack_ok, self._pack_key = ok, key
+        return self._pack_ok and a.bn.training == b.bn.training
+
     def forward(self, x):
-        return self.cv3(ops.concat([self.m(self.cv1(x)), self.cv2(x)]))
+        if not self.packed():
+            return self.cv3(ops.concat([self.m(self.cv1(x)), self.cv2(x)]))
+        # cv1 | cv2 as one GEMM; the concat buffer is written in place by its two producers (models/common.py:650 without the copy)
+        a, b = self.cv1, self.cv2
+        c_ = a.conv.weight.shape[0]
+        cat = ops.Dest(torch.empty((*x.shape[:-1], 2 * c_), dtype=x.dtype, device=x.device))
+        h, b_out = ops.dual_conv_bn_act(x, a.conv.weight, b.conv.weight, a.bn.weight, a.bn.bias, b.bn.weight, b.bn.bias,
+                                        a.bn.running_mean, a.bn.running_var, a.bn.num_batches_tracked,
+                                        b.bn.num_batches_tracked, a._act_id(), a.bn.training, a.bn.eps, a.bn.momentum,
+                                        dest=(cat, c_))
+        last = len(self.m) - 1
+        for i, blk in enumerate(self.m):
+            h = blk(h, dest=(cat, 0) if i == last else None)
+        return self.cv3(ops.cat_alias(h, b_out, cat))
 
 
 class SPP(nn.Module):

@@ -293,7 +293,7 @@ def test_uniform_loaders_are_bit_identical_to_the_general_ones(case):
             y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
             part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co + 64 * 2 * Co, device=d)
             nb = lib.conv_wgrad_workspace(desc)
-            ws = torch.empty(max(nb // 4, 1), device=d)
+            ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
             ops.conv_fwd(x, w, None, y, part, desc, st)
             ops.conv_dgrad(dy, w, dx, desc, st)
             lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)

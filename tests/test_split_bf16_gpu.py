@@ -123,7 +123,7 @@ def test_full_size_layers_split_bf16_vs_fp32_mfma(shape, mode, tol):
             dx = torch.empty_like(x)
             dw = torch.empty_like(w)
             nb = lib.conv_wgrad_workspace(desc)
-            ws = torch.empty(max(nb // 4, 1), device=d)
+            ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
             ops.conv_fwd(x, w, None, y, None, desc, st)
             ops.conv_dgrad(dy, w, dx, desc, st)
             lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)

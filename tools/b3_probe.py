@@ -33,7 +33,7 @@ for (B, H, W, Ci, Co, k, s) in SHAPES:
             t2 = timeit(lambda: ops.conv_dgrad(dy, w, dx, desc, st), 20)
             dw = torch.empty_like(w)
             nb = lib.conv_wgrad_workspace(desc)
-            ws = torch.empty(max(nb // 4, 1), device=d)
+            ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
             t3 = timeit(lambda: lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st), 20)
             res[mode] = (y.clone(), t, dx.clone(), t2, dw.clone(), t3)
         finally:

@@ -44,7 +44,7 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         nb = lib.conv_wgrad_workspace(desc)
-        ws = torch.empty(max(nb // 4, 1), device=d)
+        ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
         part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co, device=d)
         fl = 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k
         t1 = timeit(lambda: ops.conv_fwd(x, w, None, y, part, desc, st))

@@ -18,7 +18,7 @@ dy = torch.randn_like(y)
 dx = torch.empty_like(x)
 dw = torch.empty_like(w)
 nb = lib.conv_wgrad_workspace(desc)
-ws = torch.empty(max(nb // 4, 1), device=d)
+ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
 part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Co, device=d)
 for _ in range(3):
     ops.conv_fwd(x, w, None, y, part, desc, st)
