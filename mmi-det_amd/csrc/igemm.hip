@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   }
   __syncthreads();
   if (!fold_flag) return;
-  // one 32x32 sub-tile at a time (16 values per lane): the splits' loads of a sub-tile are independent of each other
+  // one 32x32 sub-tile at a time (16 values per lane); four splits' loads in flight together, summed in split order
 #pragma unroll 1
   for (int ij = 0; ij < TM * TN; ++ij) {
     const int i = ij / TN, j = ij - i * TN;
@@ -1242,13 +1242,23 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     for (int r = 0; r < 16; ++r) v[r] = 0.f;
     const int64_t e0 = (int64_t)rbase * p.Ntot + col;
 #pragma unroll 1
-    for (int z = 0; z < p.splits; ++z) {
-      const float* part = p.OUT + (int64_t)z * p.slab_stride + e0;
+    for (int z = 0; z < p.splits; z += 4) {
+      float u[4][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);
-        if (rbase + dr < p.Cout) v[r] += ld_agent(part + (int64_t)dr * p.Ntot);
+      for (int q = 0; q < 4; ++q) {
+        const float* part = p.OUT + (int64_t)min(z + q, p.splits - 1) * p.slab_stride + e0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          u[q][r] = rbase + dr < p.Cout ? ld_agent(part + (int64_t)dr * p.Ntot) : 0.f;
+        }
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (z + q < p.splits) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += u[q][r];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1866,7 +1876,11 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   }
   float* slabs = g.splits > 1 ? (float*)((char*)workspace + WG_COUNTER_BYTES) : nullptr;
   static const bool fold_off = getenv("MMIDET_WGRAD_FOLD") != nullptr && atoi(getenv("MMIDET_WGRAD_FOLD")) == 0;  // (A/B switch)
-  const bool fold = g.splits > 1 && g.mtiles * g.ntiles <= WG_MAX_TILES && !fold_off;
+  // The fold runs on ONE workgroup per tile, serially over the splits (a dependent round of loads per four of them), while
+  // the reduce kernel spreads the same reads over the whole chip: measured (profiles/r02_wgrad_fold_microbench.txt) the fold
+  // only wins up to a handful of splits, so long split lists keep the separate reduce launch.
+  static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 4;
+  const bool fold = g.splits > 1 && g.splits <= fold_max && g.mtiles * g.ntiles <= WG_MAX_TILES && !fold_off;
   WgradP p{};
   p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? slabs : dw;
   p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? slabs + wsize : dbias);

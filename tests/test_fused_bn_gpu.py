@@ -99,9 +99,14 @@ def test_bn_backward_one_call_with_split_operands(shape, act):
                        rows, C, act, 0, st)
         torch.cuda.synchronize()
         assert int(ws[:64 * 1024].view(torch.int32).abs().max()) == 0
-        # (LeakyReLU has a kink at 0: over 16.7 M elements a few sit within rounding distance of it and take the other slope
-        #  under this test's fp64 batch statistics; each costs 0.9 |dout| -- measured 2.9e-4 of the L2 norm)
-        close(dy, yr.grad, tol=1e-3 if (act == 2 and rows > 100000) else 2e-4, what='dy')
+        if act == 2 and rows > 100000:
+            # LeakyReLU has a kink at 0: over 16.7 M elements a few sit within rounding distance of it and take the other
+            # slope under this test's fp64 batch statistics; each is off by 0.9 |dout| (measured 2.9e-4 of the L2 norm)
+            from test_ops_gpu import rel_err
+            assert rel_err(dy, yr.grad) < 1e-3
+            assert int(((dy.cpu() - yr.grad).abs() > 1e-3).sum()) < 20
+        else:
+            close(dy, yr.grad, tol=2e-4, what='dy')
         close(torch.cat([dg0, dg1]), gr.grad, tol=2e-4, what='dgamma')
         close(torch.cat([db0, db1]), br.grad, tol=2e-4, what='dbeta')
 
