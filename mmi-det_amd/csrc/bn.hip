@@ -384,6 +384,8 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int n
   out[c] = (float)s;
 }
 
+__global__ void i64_increment_kernel(int64_t* c) { *c += 1; }
+
 inline int ew_blocks(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
@@ -558,7 +560,8 @@ extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ld
   float* partials = (float*)((char*)workspace + (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int));
   const BnSplitOut gs{dgamma, dbeta, dgamma1, dbeta1};
   const int nct = cdiv(C, 64), G = stat_group_size(nparts), ngroups = cdiv(nparts, G);
-  if (C <= 8 || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS) {  // the CEM's 3-channel map: one thread per row, separate fold
+  static const bool fold_off = getenv("MMIDET_BN_FOLD") != nullptr && atoi(getenv("MMIDET_BN_FOLD")) == 0;  // (A/B switch)
+  if (split == C && (C <= 8 || fold_off || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS)) {  // the CEM's 3-channel map: one thread per row, separate fold
     if (int e = mmi_bn_act_bwd_reduce(y, ldy, dout, ldd, mean_invstd, gamma, beta, partials, rows, C, act, stream)) return e;
     MMI_CHECK_ARG(split == C, "mmi_bn_act_bwd: channel split unsupported for this shape");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, dgamma, dbeta, 1);
@@ -587,6 +590,12 @@ extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* p
   MMI_CHECK_LAUNCH("mmi_colsum");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, partials, nparts, C, out);
   MMI_CHECK_LAUNCH("mmi_colsum(finalize)");
+  return MMI_OK;
+}
+
+int mmi_i64_increment(int64_t* counter, void* stream) {
+  hipLaunchKernelGGL(i64_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  MMI_CHECK_LAUNCH("mmi_i64_increment");
   return MMI_OK;
 }
 

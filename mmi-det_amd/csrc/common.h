@@ -35,6 +35,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- library-internal cross-file helpers (not part of the C ABI) ----------------------------------------------------
 // bn.hip: fp64 fold of partials[part][2][C] into out0[C] (slot 0) and out1[C] (slot 1)
 int mmi_pair_colsum(float* partials, int nparts, int C, float* out0, float* out1, void* stream);  // consumes partials
+int mmi_i64_increment(int64_t* counter, void* stream);   // bn.hip: *counter += 1
 // cem.hip: direct VALU convolutions for the 3<->24-channel CEM layers, reached through the public conv entry points
 bool mmi_smallconv_supported(const mmi_conv_desc* d);
 bool mmi_smallconv_dgrad_supported(const mmi_conv_desc* d);

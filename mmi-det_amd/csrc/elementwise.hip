@@ -211,8 +211,9 @@ __global__ void spp_bwd_kernel(const float* __restrict__ x, int ldx, const float
 // arg-max position, then every input position sums, in row-major order, the gradients of the outputs inside its window
 // that chose it; identity branch first, then the 5x5, 9x9 and 13x13 pools.
 constexpr int SPP_BYTES_PER_ELEM = 19;  // xs, rv, acc, gv (float) + rc (u8) + am (u16)
+constexpr int SPP_THREADS = 1024;       // LDS allows one workgroup per CU: a large one, so that 16 waves hide the LDS latency
 template <int CG>
-__global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat,
+__global__ __launch_bounds__(1024) void spp_bwd_tiled_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dcat,
                                                             int ldd, float* __restrict__ dx, int lddx, int H, int W, int C) {
   extern __shared__ __align__(16) unsigned char spp_smem[];
   const int HW = H * W, n = blockIdx.y, c0 = blockIdx.x * CG, E = HW * CG;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
   unsigned short* am = reinterpret_cast<unsigned short*>(gv + E);   // arg-max position h*W+w of every output pixel (HW <= 65535)
   unsigned char* rc = reinterpret_cast<unsigned char*>(am + E);     // column of the row-window maximum (W <= 255)
   const int t = threadIdx.x;
-  for (int e = t; e < E; e += 256) {
+  for (int e = t; e < E; e += SPP_THREADS) {
     const int pix = e / CG, c = e - pix * CG;
     const bool ok = c0 + c < C;
     xs[e] = ok ? x[((int64_t)n * HW + pix) * ldx + c0 + c] : 0.f;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
   __syncthreads();
   for (int pk = 0; pk < 3; ++pk) {
     const int rad = 2 + 2 * pk;
-    for (int e = t; e < E; e += 256) {
+    for (int e = t; e < E; e += SPP_THREADS) {
       const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
       float best = -INFINITY;
       int bw = -1;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
       rc[e] = (unsigned char)bw;
     }
     __syncthreads();
-    for (int e = t; e < E; e += 256) {
+    for (int e = t; e < E; e += SPP_THREADS) {
       const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
       float best = -INFINITY;
       int bh = -1;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
       gv[e] = c0 + c < C ? dcat[((int64_t)n * HW + pix) * ldd + (1 + pk) * C + c0 + c] : 0.f;
     }
     __syncthreads();
-    for (int e = t; e < E; e += 256) {
+    for (int e = t; e < E; e += SPP_THREADS) {
       const int pix = e / CG, c = e - pix * CG, h = pix / W, w = pix - h * W;
       float s = acc[e];
       for (int oh = max(h - rad, 0); oh <= min(h + rad, H - 1); ++oh)
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void spp_bwd_tiled_kernel(const float* __restr
     }
     __syncthreads();
   }
-  for (int e = t; e < E; e += 256) {
+  for (int e = t; e < E; e += SPP_THREADS) {
     const int pix = e / CG, c = e - pix * CG;
     if (c0 + c < C) dx[((int64_t)n * HW + pix) * lddx + c0 + c] = acc[e];
   }
@@ -431,7 +432,7 @@ extern "C" int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int 
     const size_t per_c = (size_t)H * W * SPP_BYTES_PER_ELEM;
     const int cg = per_c * 16 <= 150 * 1024 ? 16 : (per_c * 8 <= 150 * 1024 ? 8 : (per_c * 4 <= 150 * 1024 ? 4 : 0));
     if (cg > 0 && W <= 255 && H * W <= 65535) {
-      const dim3 grid(cdiv(C, cg), N), block(256);
+      const dim3 grid(cdiv(C, cg), N), block(SPP_THREADS);
       const size_t lds = per_c * cg;
       hipStream_t s = (hipStream_t)stream;
       static bool raised = false;   // dynamic LDS beyond 64 KB has to be allowed per kernel

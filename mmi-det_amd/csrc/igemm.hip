@@ -1636,7 +1636,8 @@ int conv_fwd_impl(const float* x, const float* w, const float* bias, const float
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
   const FwdPlan f = fwd_plan(d);
-  const bool fold = bn != nullptr && bn_fold_fits(f) &&
+  static const bool bn_fold_off = getenv("MMIDET_BN_FOLD") != nullptr && atoi(getenv("MMIDET_BN_FOLD")) == 0;  // (A/B switch)
+  const bool fold = bn != nullptr && !bn_fold_off && bn_fold_fits(f) &&
                     (bn->num_batches_tracked2 == nullptr || bn->num_batches_tracked2 == bn->num_batches_tracked + 1);
   if (fold) {
     MMI_CHECK_ARG(stat_partials && bn->mean_invstd, "%s: BN statistics need the partials buffer and mean_invstd", who);
@@ -1661,9 +1662,8 @@ int conv_fwd_impl(const float* x, const float* w, const float* bias, const float
   if (bn != nullptr && !fold) {  // (a list too long for the counter block, or counters that are not adjacent: separate fold)
     if (int e = mmi_bn_finalize(stat_partials, f.mtiles, rows, d->Cout, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
                                 bn->num_batches_tracked, bn->mean_invstd, stream)) return e;
-    if (bn->num_batches_tracked2 != nullptr) {
-      mmi_set_error("%s: two num_batches_tracked counters must be adjacent int64 words", who);
-      return MMI_ERR_ARG;
+    if (bn->num_batches_tracked2 != nullptr) {   // (rare path: the second counter takes a launch of its own)
+      if (int e = mmi_i64_increment(bn->num_batches_tracked2, stream)) return e;
     }
   }
   return MMI_OK;

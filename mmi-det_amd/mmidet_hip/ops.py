@@ -108,6 +108,8 @@ def _ohwi(w):
 
 
 OVERLAP_WGRAD = __import__("os").environ.get("MMIDET_OVERLAP_WGRAD", "1") != "0"   # weight-gradient GEMM on a side HIP stream next to dgrad
+PACK_C3 = __import__("os").environ.get("MMIDET_PACK_C3", "1") != "0"             # A/B: C3's cv1 | cv2 as one GEMM, no concat copy
+SKIP_FUSE = __import__("os").environ.get("MMIDET_SKIP_FUSE", "1") != "0"         # A/B: Bottleneck shortcut gradient in the dgrad epilogue
 SHARED_SIDE = __import__("os").environ.get("MMIDET_SHARED_SIDE", "0") == "1"   # one wgrad stream for both backbone lanes
 # Deferred join: the lane never waits for its wgrad stream per layer; the operands are kept alive in _pending and the
 # caller joins once after backward (join_pending).  Nobody may read a weight gradient before that: valid while .grad is

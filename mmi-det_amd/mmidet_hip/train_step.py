@@ -78,7 +78,8 @@ class TrainStep:
         model.nc, model.hyp, model.gr = nc, hyp, 1.0                                    # train.py:693-695
         if reducer is None:            # (a reducer has already keyed its gradient slots on the parameter addresses)
             F2.pack_qkv(model)         # q/k/v projections of the fusion transformers as one GEMM each way
-            ops.pack_pair(model)       # cv1 | cv2 of every C3 as one GEMM
+            if ops.PACK_C3:
+                ops.pack_pair(model)   # cv1 | cv2 of every C3 as one GEMM
         self.ema = ModelEMA(model) if ema else None
         self.fused = fused_optimizer
         self.optimizer, self.accumulate = build_optimizer(model, hyp, batch_size * world_size, fused=fused_optimizer,

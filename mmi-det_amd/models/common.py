@@ -76,10 +76,10 @@ class Bottleneck(nn.Module):
     def forward(self, x, dest=None):
         # the residual add rides in cv2's normalise/activate pass; its gradient in cv1's input-gradient GEMM
         if hasattr(self.cv1, 'bn') and hasattr(self.cv2, 'bn'):
-            if self.add:
+            if self.add and ops.SKIP_FUSE:
                 h, xs = self.cv1(x, skip=True)
                 return self.cv2(h, residual=xs, dest=dest)
-            return self.cv2(self.cv1(x), dest=dest)
+            return self.cv2(self.cv1(x), residual=x if self.add else None, dest=dest)
         return self.cv2(self.cv1(x), residual=x if self.add else None)        # after Model.fuse()
 
 
