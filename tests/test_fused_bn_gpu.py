@@ -107,8 +107,9 @@ def test_bn_backward_one_call_with_split_operands(shape, act):
             assert int(((dy.cpu() - yr.grad).abs() > 1e-3).sum()) < 20
         else:
             close(dy, yr.grad, tol=2e-4, what='dy')
-        close(torch.cat([dg0, dg1]), gr.grad, tol=2e-4, what='dgamma')
-        close(torch.cat([db0, db1]), br.grad, tol=2e-4, what='dbeta')
+        ptol = 1e-3 if (act == 2 and rows > 100000) else 2e-4       # (the same kink flips land in the column sums)
+        close(torch.cat([dg0, dg1]), gr.grad, tol=ptol, what='dgamma')
+        close(torch.cat([db0, db1]), br.grad, tol=ptol, what='dbeta')
 
 
 @pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (16, 20, 20, 512, 512, 3, 1), (2, 16, 16, 128, 256, 1, 1), (1, 33, 17, 96, 64, 3, 1),
