@@ -267,13 +267,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ddp = world > 1 or args.ddp
+    comm_kind = os.environ.get('MMIDET_COMM', 'native')     # 'native': mmi_comm_* (RCCL called directly); 'torch': ProcessGroupNCCL
     if ddp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        # (no device_id=: binding the group to the device at init makes every later step ~5 ms slower on this
-        # torch/RCCL; torch.cuda.set_device above already pins the rank to its GPU)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        if comm_kind == 'native':
+            # control plane (barriers, the max over ranks of a few floats, the 128-byte RCCL id) on gloo; the gradients go
+            # through the library's own communicator on the reducer's HIP stream: no ProcessGroupNCCL, no watchdog thread
+            from mmidet_hip.ddp import init_native_comm
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+            init_native_comm(rank, world)
+        else:
+            # (no device_id=: binding the group to the device at init makes every later step ~5 ms slower on this
+            # torch/RCCL; torch.cuda.set_device above already pins the rank to its GPU)
+            dist.init_process_group('nccl', rank=rank, world_size=world)
+    ctl_dev = dev if (ddp and comm_kind != 'native') else torch.device('cpu')   # where control-plane tensors live
 
     from mmidet_hip.train_step import TrainStep
     from models.yolo_test import Model
@@ -332,7 +341,7 @@ def main():
             ts.step(imgs, tg)
         te = time.perf_counter() - t
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t, te], device=dev, dtype=torch.float64)
+        t = torch.tensor([time.perf_counter() - t, te], device=ctl_dev, dtype=torch.float64)
         if ddp:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank takes the same decision
         return float(t[0]) / n * 1e3, float(t[1]) / n * 1e3
@@ -366,7 +375,7 @@ def main():
     dt = time.perf_counter() - t0
     enq_ranks = [t_enq / args.steps * 1e3]
     if world > 1:                         # host enqueue per step of every rank: eight Python threads share the box's cores
-        te = torch.tensor([t_enq / args.steps * 1e3], device=dev, dtype=torch.float64)
+        te = torch.tensor([t_enq / args.steps * 1e3], device=ctl_dev, dtype=torch.float64)
         allte = [torch.zeros_like(te) for _ in range(world)]
         dist.all_gather(allte, te)
         enq_ranks = [float(x) for x in allte]
@@ -399,14 +408,14 @@ def main():
             for _ in range(n_split):
                 loss_s, _ = ts.step(imgs, tg)
             barrier()
-            tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            tt = torch.tensor([time.perf_counter() - t1], device=ctl_dev, dtype=torch.float64)
             if ddp:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             # (an optional probe never fails the run: a non-finite loss is reported in its own object instead)
             split[name] = (float(tt) / n_split, bool(torch.isfinite(loss_s).all()), float(loss_s.detach().sum()))
         _lib.set_gemm_precision(0)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=ctl_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     assert torch.isfinite(loss).all(), 'non-finite loss in the timed region'
@@ -430,7 +439,10 @@ def main():
                        'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
                        'launch_mode_probe_ms': probes,
                        'launch_mode': ('eager, wgrad on a side stream' if not use_graph else 'whole-step hipGraph replay' if not ddp else
+                                       'whole-step hipGraph replay incl. the RCCL bucket all-reduces' if comm_kind == 'native' else
                                        'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),
+                       'gradient_transport': (None if not ddp else 'mmi_allreduce_bucket (RCCL called directly on the reducer stream)'
+                                              if comm_kind == 'native' else 'torch.distributed ProcessGroupNCCL'),
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
                        'host_enqueue_ms_per_step_per_rank': [round(v, 2) for v in enq_ranks],
                        'loss': [round(float(v), 5) for v in items.tolist()]},
@@ -469,6 +481,10 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if ddp:
+        if comm_kind == 'native':
+            from mmidet_hip import lib as _l
+            torch.cuda.synchronize()
+            _l.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -347,6 +347,22 @@ int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float
             int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes, float* out, int* nout,
             void* stream);
 
+/* ---- data-parallel communication (one process per GPU, RCCL over xGMI) ---------------------------------------------
+ * Replaces DistributedDataParallel's gradient all-reduce and initial parameter broadcast (train.py:683-686 of the
+ * reference; SURVEY.md §8e: pure data parallelism, one all-reduce of all trainable gradients per optimizer step).  RCCL is
+ * bound at run time and the copy already loaded by PyTorch-ROCm is reused; without RCCL these calls fail with a message
+ * and everything else still works.  One communicator per process.  The collectives are only enqueued on the given stream
+ * (no watchdog thread, no host synchronisation), so they overlap with backward on a side stream and may be captured into a
+ * hipGraph with the kernels around them. */
+int mmi_comm_available(void);                       /* 1 when RCCL could be bound */
+int mmi_comm_unique_id(void* id128_host);           /* rank 0: 128 bytes of HOST memory to hand to every rank */
+int mmi_comm_init(int rank, int world, const void* id128_host);   /* collective; after hipSetDevice() */
+int mmi_comm_world(void);
+int mmi_comm_rank(void);
+int mmi_allreduce_bucket(float* bucket, int64_t count, int average, void* stream);   /* in place; average: mean over ranks */
+int mmi_broadcast_bytes(void* buf, int64_t bytes, int root, void* stream);           /* in place */
+int mmi_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,10 @@
-"""Data-parallel gradient reduction for the two-stream step: one process per GPU, RCCL (torch.distributed backend
-"nccl") over xGMI, flat gradient buckets all-reduced on a side HIP stream while backward is still running.
+"""Data-parallel gradient reduction for the two-stream step: one process per GPU, RCCL over xGMI, flat gradient buckets
+all-reduced on a side HIP stream while backward is still running.
+
+Two transports, same bucket logic: "native" = the library's own communicator (mmi_comm_init / mmi_allreduce_bucket,
+include/mmidet_hip.h: RCCL called directly on the reducer's HIP stream -- no ProcessGroup, no watchdog thread, capturable into
+a hipGraph) and "torch" = torch.distributed (backend "nccl" on the GPU, "gloo" in the CPU tests).  init_native_comm() sets the
+former up over any torch.distributed group that can carry 128 bytes (gloo is enough).
 
 Replaces DistributedDataParallel at train.py:683-686 of the reference (whose DDP path cannot actually run: SURVEY.md
 §3.1 B1).  Semantics kept: every rank holds the mean over ranks of the per-rank gradients; with `loss *= world_size`
@@ -20,6 +25,24 @@ import torch.distributed as dist
 _DEBUG = __import__('os').environ.get('MMIDET_DDP_DEBUG', '')
 
 
+def init_native_comm(rank, world, group=None):
+    """Create the library's RCCL communicator for this process (idempotent).  Rank 0's 128-byte id travels over `group`
+    (any initialised torch.distributed group; not needed at world size 1).  torch.cuda.set_device() must have been called."""
+    import ctypes
+    from . import lib
+    if lib.comm_world() == world and lib.comm_rank() == rank:
+        return
+    if lib.comm_world() != 0:
+        lib.comm_destroy()
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        lib.comm_unique_id(buf)
+    box = [buf.raw if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    lib.comm_init(rank, world, ctypes.create_string_buffer(box[0], 128))
+
+
 class _Bucket:
     __slots__ = ('flat', 'params', 'pending', 'work', 'launched', 'streams')
 
@@ -38,9 +61,17 @@ class GradReducer:
     would then add the view to itself): prepare() enforces it, and gradient accumulation over several backward passes needs
     set_direct(False) (TrainStep switches by itself), where autograd accumulates into the bucket views as usual."""
 
-    def __init__(self, params, bucket_mb=256, process_group=None, direct=None):
+    def __init__(self, params, bucket_mb=256, process_group=None, direct=None, comm=None):
+        from . import lib
         self.pg = process_group
-        self.world = dist.get_world_size(process_group)
+        if comm is None:           # the library's own communicator when one has been set up, torch.distributed otherwise
+            comm = 'native' if (params[0].is_cuda and lib.comm_world() > 0) else 'torch'
+        assert comm in ('native', 'torch')
+        self.native = comm == 'native'
+        self._lib = lib
+        if self.native:
+            assert lib.comm_world() > 0, 'GradReducer(comm="native"): call ddp.init_native_comm(rank, world) first'
+        self.world = lib.comm_world() if self.native else dist.get_world_size(process_group)
         params = [p for p in params if p.requires_grad]
         bucket_mb = float(__import__('os').environ.get('MMIDET_BUCKET_MB', bucket_mb))   # (tuning override)
         cap = int(bucket_mb * 1024 * 1024) // 4
@@ -70,7 +101,7 @@ class GradReducer:
         # write the slots are the caller's
         self.set_direct(self.cuda if direct is None else direct)
         self.comm = torch.cuda.Stream(device=params[0].device) if self.cuda else None
-        self.avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else dist.ReduceOp.SUM
+        self.avg = dist.ReduceOp.AVG if (self.cuda and (self.native or dist.get_backend(process_group) == 'nccl')) else dist.ReduceOp.SUM
 
     @staticmethod
     def _make(params):
@@ -102,7 +133,10 @@ class GradReducer:
     def broadcast_parameters(self, module, src=0):
         """Rank-0 weights/buffers to every rank once (what DDP's constructor does)."""
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src, group=self.pg)
+            if self.native:        # dense storage (channels_last weights included): the bytes as they lie
+                self._lib.broadcast_bytes(t.data_ptr(), t.numel() * t.element_size(), src, torch.cuda.current_stream().cuda_stream)
+            else:
+                dist.broadcast(t.data, src, group=self.pg)
 
     def prepare(self):
         """Before every backward."""
@@ -143,7 +177,11 @@ class GradReducer:
             b.streams[cur.cuda_stream] = cur
             with torch.cuda.stream(self.comm):
                 self._order_behind_writers(b)
-                b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
+                if self.native:
+                    self._lib.allreduce_bucket(b.flat.data_ptr(), b.flat.numel(), 1, self.comm.cuda_stream)
+                    b.work = True
+                else:
+                    b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
         else:
             self._order_behind_writers_host(b)
             b.work = dist.all_reduce(b.flat, op=self.avg, group=self.pg, async_op=True)
@@ -175,6 +213,9 @@ class GradReducer:
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)
+        if self.native:
+            torch.cuda.current_stream().wait_stream(self.comm)      # one join for all buckets
+            return
         for b in self.buckets:
             if b.work is None:
                 continue
@@ -186,6 +227,9 @@ class GradReducer:
         """All buckets on the current stream, after a replayed forward+backward graph (hooks cannot fire inside a replay).
         Not overlapped with backward: 832 MB over xGMI is a few ms against a 150 ms step, and the replay saves far more."""
         for b in self.buckets:
+            if self.native:       # enqueued on the current stream: also legal inside a stream capture
+                self._lib.allreduce_bucket(b.flat.data_ptr(), b.flat.numel(), 1, torch.cuda.current_stream().cuda_stream)
+                continue
             dist.all_reduce(b.flat, op=self.avg, group=self.pg)
             if self.avg == dist.ReduceOp.SUM:
                 b.flat.div_(self.world)

@@ -111,6 +111,14 @@ _SIGS = {
     'mmi_separation_loss': (c_int, [P, P, P, P, c_int, P, P]),
     'mmi_fusion_stats_workspace': (c_size_t, []),
     'mmi_fusion_stats': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'mmi_comm_available': (c_int, []),
+    'mmi_comm_unique_id': (c_int, [P]),
+    'mmi_comm_init': (c_int, [c_int, c_int, P]),
+    'mmi_comm_world': (c_int, []),
+    'mmi_comm_rank': (c_int, []),
+    'mmi_allreduce_bucket': (c_int, [P, c_int64, c_int, P]),
+    'mmi_broadcast_bytes': (c_int, [P, c_int64, c_int, P]),
+    'mmi_comm_destroy': (c_int, []),
     'mmi_sgd_ema_step': (c_int, [P, P, c_int, P, P]),
     'mmi_sobel_add_fwd': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_sobel_add_bwd_workspace': (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -119,7 +127,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

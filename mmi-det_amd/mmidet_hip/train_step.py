@@ -91,6 +91,7 @@ class TrainStep:
         self.use_graph = graph
         self.defer_join = defer_join
         self._graph = None
+        self._graph_has_collectives = False
         assert not (graph and self.accumulate != 1), 'graph mode captures one full step: accumulate must be 1'
         assert not (graph and not fused_optimizer), 'graph mode needs the fused optimizer (device-resident hyper-parameters)'
 
@@ -180,9 +181,9 @@ class TrainStep:
         self._targets.copy_(targets, non_blocking=True)
         self.optimizer.upload_hyper()
         self._graph.replay()
-        if self.reducer is not None:
-            # data parallel: the graph holds forward+backward only (gradients land in the reducer's flat buckets); the
-            # collectives and the one-launch optimizer follow on the same stream
+        if self.reducer is not None and not self._graph_has_collectives:
+            # data parallel over torch.distributed: the graph holds forward+backward only (gradients land in the reducer's
+            # flat buckets); the collectives and the one-launch optimizer follow on the same stream
             self.reducer.reduce_now()
             self._update(in_capture=True)
         self.ni += 1
@@ -218,10 +219,16 @@ class TrainStep:
         self._graph = torch.cuda.CUDAGraph()
         if self.reducer is not None:
             self.reducer.enabled = False                   # no collectives inside the capture: see _graph_step
-        # data parallel: RCCL's watchdog thread polls events of finished collectives; under the default (global) capture
-        # error mode that query aborts the process while this thread is capturing
-        mode = 'thread_local' if self.reducer is not None else 'global'
+        # The library's own communicator (ddp.init_native_comm) enqueues RCCL on the capturing stream like any kernel: the bucket
+        # all-reduces and the optimizer are part of the graph, a step is ONE replay.  Over torch.distributed they stay
+        # outside: ProcessGroupNCCL's watchdog thread polls events of finished collectives, and under the default (global)
+        # capture error mode that query aborts the process while this thread is capturing.
+        native = self.reducer is not None and getattr(self.reducer, 'native', False)
+        self._graph_has_collectives = native
+        mode = 'thread_local' if (self.reducer is not None and not native) else 'global'
         with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._loss, self._items = self._body(self._imgs, self._targets, reduce=False)
-            if self.reducer is None:
+            if native:
+                self.reducer.reduce_now()
+            if self.reducer is None or native:
                 self._update(in_capture=True)

@@ -72,3 +72,13 @@ def synth_batch(bs, size, nc, per_image=8, seed=0):
     t[:, 2:4] = 0.1 + 0.8 * u[:, 1:3]
     t[:, 4:6] = 0.02 + 0.30 * u[:, 3:5]
     return torch.from_numpy(img), torch.from_numpy(t)
+
+
+def signs(n, name):
+    """A fixed +-1 vector (float64 torch tensor) from an integer hash of (name, index): random projections of gradient
+    tensors that both sides of a fixture can regenerate (oracle/gen_fp64_fullsize.py)."""
+    with np.errstate(over='ignore'):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(zlib.crc32(name.encode()) * 0x10001 + 12345)
+        z = (z ^ (z >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
+        bit = (z >> np.uint64(40)) & np.uint64(1)
+    return torch.from_numpy(bit.astype(np.float64) * 2.0 - 1.0)

@@ -305,6 +305,53 @@ def test_data_parallel_reducer_corner_cases():
         dist.destroy_process_group()
 
 
+def test_native_comm_transport_world1():
+    """The library's own communicator (mmi_comm_init / mmi_allreduce_bucket / mmi_broadcast_bytes: RCCL called directly on the
+    reducer's HIP stream, no ProcessGroup) at world size 1: the raw collectives, the eager data-parallel step and the hipGraph
+    form -- which with this transport holds the bucket all-reduces and the optimizer, one replay per step -- all equal the
+    single-GPU step."""
+    from mmidet_hip import lib, ops
+    from mmidet_hip.ddp import GradReducer, init_native_comm
+    assert lib.comm_available() == 1
+    init_native_comm(0, 1)
+    try:
+        assert lib.comm_world() == 1 and lib.comm_rank() == 0
+        t = torch.arange(1000, dtype=torch.float32, device=dev())
+        st = torch.cuda.current_stream().cuda_stream
+        lib.allreduce_bucket(t.data_ptr(), t.numel(), 1, st)
+        lib.broadcast_bytes(t.data_ptr(), t.numel() * 4, 0, st)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
+        # eager
+        m1, ts1, cfg = make(graph=False)
+        m2, ts2, _ = make(graph=False)
+        red = ts2.reducer = GradReducer(list(m2.parameters()))
+        assert red.native and red.direct and red.world == 1
+        red.broadcast_parameters(m2)
+        for it in range(3):
+            imgs, tg = batch(cfg, 100 + it)
+            l1, _ = ts1.step(imgs, tg)
+            l2, _ = ts2.step(imgs, tg)
+            assert torch.equal(l1, l2), 'the step is deterministic and world size 1 averages nothing: bit-identical'
+        assert torch.equal(m1.model[1].conv.weight, m2.model[1].conv.weight)
+        ops.GRAD_SLOTS.clear()
+        # hipGraph with the collectives inside
+        m1, ts1, cfg = make(graph=True)
+        m2, ts2, _ = make(graph=True)
+        ts2.reducer = GradReducer(list(m2.parameters()))
+        for it in range(3):
+            imgs, tg = batch(cfg, 110 + it)
+            l1, _ = ts1.step(imgs, tg)
+            l2, _ = ts2.step(imgs, tg)
+            close(l1, l2, what='graph loss %d' % it, tol=1e-5)
+        assert ts2._graph_has_collectives
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=1e-5)
+    finally:
+        ops.GRAD_SLOTS.clear()
+        torch.cuda.synchronize()
+        lib.comm_destroy()
+
+
 def test_training_overfits_one_batch():
     """End-to-end sanity of the step (forward, loss, backward, fused SGD+EMA, BN running stats, warm-up schedule): 40 steps on
     one batch must bring the detection loss down steadily (measured 0.194 -> 0.141) and leave every parameter and buffer
