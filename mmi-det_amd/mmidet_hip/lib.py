@@ -160,3 +160,19 @@ def register(sigs):
 
 
 register(dict(_SIGS))
+
+# Planner settings change which schedule (and how much workspace) a shape gets: callers that cache planner answers per shape
+# (ops.fwd_plan ...) key them on this counter.
+plan_epoch = [0]
+
+
+def _bump(fn):
+    def wrapped(*a):
+        plan_epoch[0] += 1
+        return fn(*a)
+    wrapped.__name__ = getattr(fn, '__name__', 'setter')
+    return wrapped
+
+
+for _name in ('set_streamk_slots', 'set_tile_override', 'set_gemm_precision', 'set_uniform_loaders'):
+    globals()[_name] = _bump(globals()[_name])

@@ -11,7 +11,14 @@ _scratch = {}
 _retired = []     # workspaces replaced by a larger one: kept until the streams that may still use them have been joined
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of the current torch stream as an integer (the raw getter is ~10x cheaper than building a Stream object;
+    it is called several thousand times per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -50,14 +57,22 @@ def zeroed_scratch(nbytes, device, stream=None, tag=0):
 
 def conv_fwd(x, w, bias, y, part, d, s):
     """mmi_conv_fwd on tensors (None -> NULL) with the stream-K workspace the shape asks for."""
-    nb = lib.conv_fwd_workspace(d)
+    nb = fwd_plan(d)[0]
     ws = zeroed_scratch(nb, x.device, s) if nb else None
     lib.conv_fwd(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                  part.data_ptr() if part is not None else None, ws.data_ptr() if nb else None, nb, d, s)
 
 
+_dgrad_ws = {}
+_wgrad_ws = {}
+_bnbwd_ws = {}
+
+
 def conv_dgrad(dy, w, dx, d, s):
-    nb = lib.conv_dgrad_workspace(d)
+    k = _desc_key(d)
+    nb = _dgrad_ws.get(k)
+    if nb is None:
+        nb = _dgrad_ws[k] = lib.conv_dgrad_workspace(d)
     ws = zeroed_scratch(nb, dy.device, s) if nb else None
     lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, d, s)
 
@@ -67,6 +82,8 @@ def rows_of(t):
     uniform row stride ld."""
     assert t.dtype == torch.float32 and t.is_cuda, 'mmidet_hip ops need fp32 tensors on the MI355X'
     C = t.shape[-1]
+    if t.is_contiguous():          # the common case
+        return t, C
     if t.dim() == 1:
         return (t if t.stride(0) == 1 else t.contiguous()), C
     ok = t.stride(-1) == 1 or C == 1
@@ -158,7 +175,10 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     dw = grad_like(w)
     db = (grad_like(bias) if bias is not None else torch.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
     dbp = db.data_ptr() if want_bias else None
-    nbytes = lib.conv_wgrad_workspace(d)
+    k = _desc_key(d)
+    nbytes = _wgrad_ws.get(k)
+    if nbytes is None:
+        nbytes = _wgrad_ws[k] = lib.conv_wgrad_workspace(d)
     if overlap:
         main, side = torch.cuda.current_stream(), _side_stream(w.device)
         ws = zeroed_scratch(nbytes, w.device, side.cuda_stream, tag='w') if nbytes else None
@@ -218,13 +238,36 @@ def _dest_view(dest, shape):
     return out
 
 
+_plan_cache = {}
+
+
+def _desc_key(d):
+    return (lib.plan_epoch[0], d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.ldx, d.ldy)
+
+
+def fwd_plan(d):
+    """(workspace bytes, statistics row blocks) of a forward descriptor: planner queries cached per shape (two C calls per
+    convolution per step otherwise)."""
+    k = _desc_key(d)
+    v = _plan_cache.get(k)
+    if v is None:
+        v = _plan_cache[k] = (lib.conv_fwd_workspace(d), lib.conv_fwd_row_blocks(d))
+    return v
+
+
+def bn_bwd_ws(rows, c):
+    v = _bnbwd_ws.get((rows, c))
+    if v is None:
+        v = _bnbwd_ws[(rows, c)] = lib.bn_act_bwd_workspace(rows, c)
+    return v
+
+
 def _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, nbt2, s):
     """conv + BatchNorm statistics (training: folded inside the conv launch) -> mean_invstd (2*cout)."""
     mi = torch.empty(2 * cout, dtype=x.dtype, device=x.device)
-    nb = lib.conv_fwd_workspace(d)
+    nb, nrb = fwd_plan(d)
     ws = zeroed_scratch(nb, x.device, s) if nb else None
     if training:
-        nrb = lib.conv_fwd_row_blocks(d)
         part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows (the CEM's separate fold)
         bn = lib.BnStats(eps, momentum, rmean.data_ptr(), rvar.data_ptr(), nbt.data_ptr() if nbt is not None else None,
                          nbt2.data_ptr() if nbt2 is not None else None, mi.data_ptr())
@@ -286,7 +329,7 @@ class _ConvBnAct(Function):
         cout = d.Cout
         rows = d.N * d.Ho * d.Wo
         s = _stream()
-        nbw = lib.bn_act_bwd_workspace(rows, cout)
+        nbw = bn_bwd_ws(rows, cout)
         ws = zeroed_scratch(nbw, x.device, s, tag='bn')
         dy = torch.empty_like(y)
         dgamma = grad_like(gamma)
@@ -356,7 +399,7 @@ class _DualConvBnAct(Function):
         cout, rows, s = 2 * c_, d.N * d.Ho * d.Wo, _stream()
         da, lda = rows_of(da)
         db, ldb = rows_of(db)
-        nbw = lib.bn_act_bwd_workspace(rows, cout)
+        nbw = bn_bwd_ws(rows, cout)
         ws = zeroed_scratch(nbw, x.device, s, tag='bn')
         dy = torch.empty_like(y)
         dg1, dbt1, dg2, dbt2 = grad_like(g1), grad_like(b1), grad_like(g2), grad_like(b2)

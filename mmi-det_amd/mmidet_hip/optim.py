@@ -157,6 +157,9 @@ class FusedSGDEMA:
                 p.grad = None
             elif p.grad is not None:
                 p.grad.zero_()
-        for p in self.model.parameters():   # parameters in no group (pos_emb, sobel_factor) still receive gradients
-            if p.grad is not None and set_to_none:
+        if getattr(self, '_ungrouped', None) is None:   # parameters in no group (pos_emb, sobel_factor) still receive gradients
+            ids = {id(p) for p in self._sgd_params}
+            self._ungrouped = [p for p in self.model.parameters() if id(p) not in ids]
+        if set_to_none:
+            for p in self._ungrouped:
                 p.grad = None

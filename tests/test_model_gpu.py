@@ -308,6 +308,9 @@ def test_yolov5l_640_gradients_against_the_fp64_arbiter():
     assert set(names) == set(g64)
     for n, nrm, pr in zip(names, fix['norms'], fix['projs']):
         g = g64[n].reshape(-1)
+        if nrm < 1e-12:       # (e.g. key_proj.bias: mathematically zero -- softmax is shift-invariant -- so pure rounding noise)
+            assert float(g.norm()) < 1e-12, n
+            continue
         assert abs(float(g.norm()) - nrm) <= 1e-8 * nrm + 1e-300, n
         for k in range(len(pr)):
             got = float((g * portable_init.signs(g.numel(), '%s#%d' % (n, k))).sum())
