@@ -116,6 +116,7 @@ class ConvTimer:
         wrap('conv_fwd', lambda a: fl(desc_of(a)))
         wrap('conv_dgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad', lambda a: fl(desc_of(a)))
+        wrap('conv_wgrad_tab', lambda a: fl(desc_of(a)), 'conv_wgrad')
         # the transformer blocks' Linear layers with fused epilogues (same kernels, counted with the convolutions)
         wrap('linear_fwd_fused', lambda a: fl(desc_of(a)), 'conv_fwd')
         wrap('linear_dgrad_fused', lambda a: fl(desc_of(a)), 'conv_dgrad')
@@ -234,6 +235,8 @@ def main():
                          'products (each product exact).  Both: full-depth gradients as the fp32 path over four seeds. '
                          'bf16x3: two terms, three products (GEMM 4.5e-6, full-depth gradients ~1e-2)')
     ap.add_argument('--no-split-probe', action='store_true', help='skip the extra split-bf16 measurement after the timed region')
+    ap.add_argument('--h2d', action='store_true', help='also time the step fed from HOST memory through the pinned, double-buffered '
+                                                       'feeder (mmidet_hip.feed): the PCIe-inclusive rate, reported beside `value`')
     ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
@@ -414,6 +417,31 @@ def main():
             # (an optional probe never fails the run: a non-finite loss is reported in its own object instead)
             split[name] = (float(tt) / n_split, bool(torch.isfinite(loss_s).all()), float(loss_s.detach().sum()))
         _lib.set_gemm_precision(0)
+    pcie = None
+    if args.h2d:
+        # Not `value` (whose inputs are resident in HBM by contract): the same step with every batch coming from host memory.
+        from mmidet_hip.feed import PairedBatchFeeder
+        ts.use_graph = False
+        host = [(imgs.cpu().pin_memory(), tg.cpu()), (imgs.flip(0).cpu().pin_memory(), tg.cpu())]   # as a pin_memory DataLoader
+        n_h2d = args.steps + 2
+
+        def gen():
+            for i in range(n_h2d):
+                yield host[i & 1]
+        feeder = PairedBatchFeeder(gen(), dev)
+        barrier()
+        t1 = None
+        for i, (bi, bt) in enumerate(feeder):
+            if i == 2:                       # two untimed steps fill the pipeline
+                barrier()
+                t1 = time.perf_counter()
+            ts.step(bi, bt)
+        barrier()
+        th = (time.perf_counter() - t1) / args.steps
+        pcie = {'value': round(world * bs / th, 3), 'unit': 'paired img/s', 'ms_per_step': round(th * 1e3, 3),
+                'h2d_MB_per_step': round(feeder.bytes_copied / n_h2d / 1e6, 2),
+                'what': 'same step, every batch copied from pinned host memory as uint8 by mmidet_hip.feed.PairedBatchFeeder '
+                        '(double-buffered on a copy stream, overlapped with the previous step)'}
     if world > 1:
         t = torch.tensor([dt], device=ctl_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -476,6 +504,8 @@ def main():
                         'off by default, see DESIGN.md',
                 **{k: {'value': round(world * bs / v[0], 3), 'unit': 'paired img/s', 'ms_per_step': round(v[0] * 1e3, 3),
                        'loss_finite': v[1], 'last_loss': v[2], 'arithmetic': what[k]} for k, v in split.items()}}
+        if pcie is not None:
+            out['pcie_inclusive'] = pcie
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         sys.stdout.flush()

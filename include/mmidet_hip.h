@@ -137,6 +137,15 @@ int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, 
  * ordered on one stream -- and the split-K slabs behind them: the workgroup that completes a tile's last split sums the
  * splits in split order (deterministic), so no reduce launch follows. */
 size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d);
+/* Optional: the layer's pixel table (for every output pixel the byte offset of its top-left source position and the mask
+ * of taps that leave the image).  It depends on the descriptor only, not on data: build it ONCE per geometry
+ * (mmi_conv_wgrad_table_bytes(d) bytes, 8-byte aligned; 0 = this shape uses none) and hand it to mmi_conv_wgrad_tab, whose
+ * kernel then copies 32 entries per K slab instead of computing them next to its MFMA stream (~100 VALU instructions per
+ * slab).  mmi_conv_wgrad is the same call with table = NULL. */
+size_t mmi_conv_wgrad_table_bytes(const mmi_conv_desc* d);
+int mmi_conv_wgrad_table_build(void* table, const mmi_conv_desc* d, void* stream);
+int mmi_conv_wgrad_tab(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                       const void* table, const mmi_conv_desc* d, void* stream);
 int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                    const mmi_conv_desc* d, void* stream);
 

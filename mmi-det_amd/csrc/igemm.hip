@@ -845,6 +845,9 @@ struct WgradP {
   int* cnt;
   float* DW;
   float* DB;
+  // TAB loaders: the per-pixel {source offset, invalid-tap mask} table of the layer's geometry, precomputed once
+  // (mmi_conv_wgrad_table_build: it depends on shapes and strides only, not on data); null = built in the kernel, slab by slab
+  const uint2* tab;
 };
 
 // LDS stages of the wgrad kernel: single-buffered (3+ workgroups per CU, +3..10 % measured on the 3x3 layers) except for
@@ -955,8 +958,21 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   // 1x1 stride-1 layers: x rows are as linear in the pixel index as the dy rows, so they take the same re-based resource
   // and no table at all
   const bool lin1w = TAB && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;  // uniform
+  // With a precomputed table the wave whose turn it is just copies the slab's 32 entries: one 8-byte load per lane, issued a
+  // slab early (fetch_table) and stored when the slab's MFMAs are done (build_table) -- 2 instructions instead of ~100 VALU.
+  const bool gtab = TAB && p.tab != nullptr;  // uniform
+  uint2 tnext = {0u, 0xFFFFFFFFu};
+  auto fetch_table = [&](int j) {
+    if constexpr (TAB) {
+      if (gtab && !lin1w && wave == (j & 3) && lane < BK) tnext = p.tab[(int64_t)kbeg + (int64_t)j * BK + lane];
+    }
+  };
   auto build_table = [&](int j) {
     if constexpr (TAB) {
+      if (gtab) {
+        if (!lin1w && wave == (j & 3) && lane < BK) ptab[j & 1][lane] = tnext;
+        return;
+      }
       if (!lin1w && wave == (j & 3) && lane < BK) {
         uint2 e = {0u, 0xFFFFFFFFu};
         if (tpix < kend) {
@@ -1109,7 +1125,9 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   const int nk = (kend - kbeg + BK - 1) / BK;
   const int l31 = lane & 31, lh = lane >> 5;
   if constexpr (TAB) {
+    fetch_table(0);
     build_table(0);
+    fetch_table(1);
     build_table(1);
     __syncthreads();
   }
@@ -1120,6 +1138,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     advance();  // unconditional prefetch of the next slab (lanes past the split's end read the zero source)
+    fetch_table(ks + 2);
     const float* As = smem + (MMI_WGRAD_STAGES == 2 ? (ks & 1) : 0) * STAGE;
     const float* Bs = As + A_ELEMS;
     if constexpr (PREC >= 1) {
@@ -1271,6 +1290,27 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     for (int z = 0; z < p.splits; ++z) s += ld_agent(p.OUTB + (int64_t)z * p.slab_stride + m0 + t);
     p.DB[m0 + t] = s;
   }
+}
+
+// The pixel table of a layer geometry, entry p = output pixel p: exactly what wgrad_kernel's in-kernel builder produces
+// (source byte offset of the pixel's top-left tap incl. the margin; bit t set = tap t leaves the image), followed by
+// invalid entries for the slabs a split may prefetch past the last pixel.
+__global__ void wgrad_table_kernel(uint2* __restrict__ tab, int Mpix, int total, int Ho, int Wo, int H, int W, int KH, int KW,
+                                   int stride, int pad, int ldx) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  uint2 e = {0u, 0xFFFFFFFFu};
+  if (p < Mpix) {
+    const int howo = Ho * Wo, img = p / howo, rem = p - img * howo, oh = rem / Wo, ow = rem - oh * Wo;
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    e.x = (uint32_t)(((((int64_t)img * H + ih0 + KH) * W + iw0 + KW) * ldx) * 4);
+    uint32_t bw = 0, m = 0;
+    for (int kw = 0; kw < KW; ++kw) bw |= ((unsigned)(iw0 + kw) >= (unsigned)W ? 1u : 0u) << kw;
+    const uint32_t roww = (1u << KW) - 1u;
+    for (int kh = 0; kh < KH; ++kh) m |= (((unsigned)(ih0 + kh) >= (unsigned)H) ? roww : bw) << (kh * KW);
+    e.y = m;
+  }
+  tab[p] = e;
 }
 
 // out = sum over splits of slabs[z]: 16-byte lanes, 4 independent loads in flight per thread (HBM-bound)
@@ -1853,8 +1893,50 @@ extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
   return body ? WG_COUNTER_BYTES + body : 0;
 }
 
+namespace {
+// does this shape run the pixel-table loaders with a table (not the 1x1 stride-1 layers, whose x rows need none)?
+bool wgrad_uses_table(const mmi_conv_desc* d) {
+  if (mmi_smallconv_supported(d)) return false;
+  const WgPlan g = wgrad_plan(d);
+  if (!(g.vec && g_uniform_loaders && g_gemm_prec == 0 && d->KH * d->KW <= 32)) return false;
+  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0) return false;
+  const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
+  return (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4 < (1LL << 31);
+}
+int64_t wgrad_table_entries(const mmi_conv_desc* d) { return (int64_t)d->N * d->Ho * d->Wo + 4 * BK; }
+}  // namespace
+
+extern "C" size_t mmi_conv_wgrad_table_bytes(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_wgrad_table_bytes") != MMI_OK || !wgrad_uses_table(d)) return 0;
+  return (size_t)wgrad_table_entries(d) * sizeof(uint2);
+}
+
+extern "C" int mmi_conv_wgrad_table_build(void* table, const mmi_conv_desc* d, void* stream) {
+  if (int e = check_desc(d, "mmi_conv_wgrad_table_build")) return e;
+  MMI_CHECK_ARG(table != nullptr && ((uintptr_t)table & 7) == 0, "mmi_conv_wgrad_table_build: null or misaligned table");
+  const int total = (int)wgrad_table_entries(d);
+  hipLaunchKernelGGL(wgrad_table_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (uint2*)table,
+                     d->N * d->Ho * d->Wo, total, d->Ho, d->Wo, d->H, d->W, d->KH, d->KW, d->stride, d->pad, d->ldx);
+  MMI_CHECK_LAUNCH("mmi_conv_wgrad_table_build");
+  return MMI_OK;
+}
+
+namespace {
+int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                    const void* table, const mmi_conv_desc* d, void* stream);
+}
 extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  return conv_wgrad_impl(dy, x, dw, dbias, workspace, workspace_bytes, nullptr, d, stream);
+}
+extern "C" int mmi_conv_wgrad_tab(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
+                                  size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream) {
+  return conv_wgrad_impl(dy, x, dw, dbias, workspace, workspace_bytes, table, d, stream);
+}
+
+namespace {
+int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                    const void* table, const mmi_conv_desc* d, void* stream) {
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
   if (mmi_smallconv_supported(d) && dbias == nullptr) {
@@ -1905,6 +1987,7 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
     if (x_bytes < (1LL << 31)) {
       tab = true;
       p.x_bytes = (uint32_t)x_bytes;
+      p.tab = (const uint2*)table;   // (null: the kernel builds its table slab by slab)
     }
   }
 #define LAUNCHW(BM_, BN_, VEC_) \
@@ -1944,3 +2027,4 @@ extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float*
   }
   return MMI_OK;
 }
+}  // namespace

@@ -65,6 +65,9 @@ _SIGS = {
     'mmi_conv_dgrad': (c_int, [P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_wgrad': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad_table_bytes': (c_size_t, [POINTER(ConvDesc)]),
+    'mmi_conv_wgrad_table_build': (c_int, [P, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad_tab': (c_int, [P, P, P, P, P, c_size_t, P, POINTER(ConvDesc), P]),
     'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
     'mmi_bn_eval_stats': (c_int, [P, P, c_int, c_float, P, P]),
     'mmi_bn_act_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, c_int64, c_int, c_int, P]),

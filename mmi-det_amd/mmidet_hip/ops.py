@@ -167,6 +167,31 @@ def grad_like(t):
     return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
 
 
+_wgrad_tabs = {}       # (device, geometry) -> uint8 tensor holding the layer's pixel table
+_wgrad_tab_use = {}    # descriptor -> table bytes (0: this shape takes none)
+WGRAD_TABLE = __import__("os").environ.get("MMIDET_WGRAD_TABLE", "1") != "0"      # A/B: precomputed pixel tables for wgrad
+
+
+def wgrad_table(d, device):
+    """The precomputed pixel table of this layer geometry (include/mmidet_hip.h: mmi_conv_wgrad_table_build) or None.  Built
+    once, on the current stream, the first time a geometry is seen; it depends on shapes and strides only."""
+    if not WGRAD_TABLE:
+        return None
+    k = _desc_key(d)
+    nb = _wgrad_tab_use.get(k)
+    if nb is None:
+        nb = _wgrad_tab_use[k] = lib.conv_wgrad_table_bytes(d)
+    if nb == 0:
+        return None
+    g = (device, d.N, d.H, d.W, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad, d.ldx)
+    t = _wgrad_tabs.get(g)
+    if t is None or t.numel() < nb:
+        t = torch.empty(nb, dtype=torch.uint8, device=device)
+        lib.conv_wgrad_table_build(t.data_ptr(), d, _stream())
+        _wgrad_tabs[g] = t
+    return t
+
+
 def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     """dw = dy^T x.  With overlap=True the kernel is enqueued on the side stream behind everything already on the
     current stream; the caller must `_join_side()` before the current stream (or anyone else) touches dw.  dgrad and wgrad
@@ -179,19 +204,21 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     nbytes = _wgrad_ws.get(k)
     if nbytes is None:
         nbytes = _wgrad_ws[k] = lib.conv_wgrad_workspace(d)
+    tab = wgrad_table(d, w.device)
+    tabp = tab.data_ptr() if tab is not None else None
     if overlap:
         main, side = torch.cuda.current_stream(), _side_stream(w.device)
         ws = zeroed_scratch(nbytes, w.device, side.cuda_stream, tag='w') if nbytes else None
         side.wait_stream(main)
-        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
-                       d, side.cuda_stream)
+        lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
+                           tabp, d, side.cuda_stream)
         if DEFER_JOIN:
             _pending.append((dy, x))
             _pending_sides[side.cuda_stream] = side
     else:
         ws = zeroed_scratch(nbytes, w.device, tag='w') if nbytes else None
-        lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
-                       d, _stream())
+        lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
+                           tabp, d, _stream())
     return (dw, db) if want_bias else dw
 
 

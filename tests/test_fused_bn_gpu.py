@@ -145,6 +145,36 @@ def test_wgrad_fold_inside_the_launch(case, monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (2, 21, 23, 32, 64, 3, 2), (16, 40, 40, 256, 256, 3, 1), (1, 33, 17, 96, 64, 3, 1),
+                                  (3, 9, 50, 64, 128, 3, 2)])
+def test_wgrad_precomputed_pixel_table_is_bit_identical(case):
+    """mmi_conv_wgrad_tab with the layer's precomputed pixel table against the in-kernel table builder (table = NULL): the
+    same entries, so dw must be equal bit for bit -- borders, ragged last slab, stride 2 and split-K included."""
+    from mmidet_hip import lib, ops
+    N, H, W, Ci, Co, k, s = case
+    d = dev()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, generator=g).to(d)
+    desc = ops._desc((N, H, W, Ci), Co, k, s, Ci, Co)
+    dy = torch.randn(N, desc.Ho, desc.Wo, Co, generator=g).to(d)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.conv_wgrad_workspace(desc)
+    ws = torch.zeros(max(nb, 16), dtype=torch.uint8, device=d)
+    tb = lib.conv_wgrad_table_bytes(desc)
+    assert tb > 0
+    tab = torch.empty(tb, dtype=torch.uint8, device=d)
+    lib.conv_wgrad_table_build(tab.data_ptr(), desc, st)
+    outs = []
+    for t in (None, tab.data_ptr()):
+        dw = torch.empty(Co, k, k, Ci, device=d)
+        lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, t, desc, st)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    # 1x1 stride-1 layers take no table
+    assert lib.conv_wgrad_table_bytes(ops._desc((N, H, W, Ci), Co, 1, 1, Ci, Co)) == 0
+
+
 def _c3(c1, c2, n, shortcut, seed):
     from models.common import C3
     torch.manual_seed(seed)

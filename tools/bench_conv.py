@@ -34,7 +34,7 @@ def main():
         lib.set_uniform_loaders(int(os.environ['BENCH_UNI']))
     d = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
-    print('%-34s %9s %9s %9s   (TFLOP/s; ms)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
+    print('%-34s %9s %9s %9s %9s   (TFLOP/s; ms)' % ('shape', 'fwd', 'dgrad', 'wgrad', 'wgrad+tab'))
     for (B, H, W, Ci, Co, k, s) in SHAPES:
         x = torch.randn(B, H, W, Ci, device=d)
         w = torch.randn(Co, k, k, Ci, device=d) * 0.05
@@ -50,8 +50,14 @@ def main():
         t1 = timeit(lambda: ops.conv_fwd(x, w, None, y, part, desc, st))
         t2 = timeit(lambda: ops.conv_dgrad(dy, w, dx, desc, st))
         t3 = timeit(lambda: lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st))
-        print('%-34s %9.1f %9.1f %9.1f   (%.3f %.3f %.3f)' % (str((B, H, W, Ci, Co, k, s)), fl / t1 / 1e9, fl / t2 / 1e9,
-                                                                fl / t3 / 1e9, t1, t2, t3), flush=True)
+        tb = lib.conv_wgrad_table_bytes(desc)
+        t4 = t3
+        if tb:      # the same with the layer's precomputed pixel table
+            tab = torch.empty(tb, dtype=torch.uint8, device=d)
+            lib.conv_wgrad_table_build(tab.data_ptr(), desc, st)
+            t4 = timeit(lambda: lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, tab.data_ptr(), desc, st))
+        print('%-34s %9.1f %9.1f %9.1f %9.1f   (%.3f %.3f %.3f %.3f)' % (str((B, H, W, Ci, Co, k, s)), fl / t1 / 1e9, fl / t2 / 1e9,
+                                                                          fl / t3 / 1e9, fl / t4 / 1e9, t1, t2, t3, t4), flush=True)
 
 
 if __name__ == '__main__':
