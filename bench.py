@@ -114,6 +114,7 @@ class ConvTimer:
         def desc_of(a):
             return [x for x in a if hasattr(x, 'Cout')][0]
         wrap('conv_fwd', lambda a: fl(desc_of(a)))
+        wrap('conv_bn_fwd', lambda a: fl(desc_of(a)), 'conv_fwd')        # (training Conv: statistics folded in the same launch)
         wrap('conv_dgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad_tab', lambda a: fl(desc_of(a)), 'conv_wgrad')
