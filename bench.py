@@ -482,8 +482,21 @@ def main():
                 with open(args.dump_gemm, 'w') as fh:
                     fh.write('\n'.join(timer.by_shape()) + '\n')
             ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+            # HBM traffic of the igemm family per step from the PMC counters: collected off line (two rocprofv3 --pmc passes over
+            # this very command, tools/pmc_step.sh) and committed under profiles/; reported only for the workload it was taken on
+            traffic = None
+            try:
+                with open(os.path.join(REPO, 'profiles', 'r02_pmc_step_traffic.json')) as fh:
+                    pt = json.load(fh)
+                if pt.get('workload') == args.workload and bs == WORKLOADS[args.workload][5]:
+                    traffic = {'read_MB_per_step': pt['read_MB_per_step'].get('igemm'), 'write_MB_per_step': pt['write_MB_per_step'].get('igemm'),
+                               'unit': 'MB of HBM/fabric traffic of the igemm family per training step (PMC: FETCH_SIZE x2 + WRITE_SIZE)',
+                               'all_families_MB_per_step': pt.get('total_MB_per_step'),
+                               'source': 'profiles/r02_pmc_step_traffic.json (tools/pmc_step.sh)'}
+            except (OSError, ValueError, KeyError):
+                pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                                'kernel': 'igemm_kernel / wgrad_kernel (fp32 MFMA implicit GEMM: conv+linear fwd, dgrad, wgrad)',
                                'launches_per_step': len(timer.recs) // max(roof_steps, 1),
                                'gemm_busy_ms_per_step': round(tot_ms / roof_steps, 3),
