@@ -161,6 +161,65 @@ class ConvTimer:
         return tot_f, busy, per
 
 
+def hbm_ops(model, bs, size, dev):
+    """The memory-bound fusion ops of the path (SURVEY.md §8a rows 3, 7, 8, 10, 12, 13 and the BatchNorm passes) timed stand-alone
+    with HIP events on the current stream at this workload's shapes: achieved GB/s of ALGORITHMIC traffic (every input read
+    once, every output written once) against the 8 TB/s HBM peak of MI355X_MICROARCH.md."""
+    from mmidet_hip import fusion_ops as F2, ops
+    c2 = model.model[2].cv3.conv.weight.shape[0] if hasattr(model.model[2], 'cv3') else 128      # P2 width (128 at yolov5l)
+    h2 = size // 4
+    out = {}
+
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e-3
+
+    def row(name, nbytes, fn):
+        t = timed(fn)
+        out[name] = {'algorithmic_MB': round(nbytes / 1e6, 1), 'us': round(t * 1e6, 1), 'GB/s': round(nbytes / t / 1e9, 0),
+                     'frac_of_8TB/s': round(nbytes / t / 8e12, 3)}
+    with torch.no_grad():
+        a = torch.randn(bs, h2, h2, c2, device=dev)
+        b = torch.randn(bs, h2, h2, c2, device=dev)
+        nb = a.numel() * 4
+        tok = F2.pool_tokens(a, b)
+        row('avgpool8 P2 (both streams -> tokens)', 2 * nb + tok.numel() * 4, lambda: F2.pool_tokens(a, b))
+        t1, _ = F2.split_tokens(tok)
+        row('bilinear 8x8 upsample + Add2 P2', 2 * nb + t1.numel() * 4, lambda: F2.upsample_add(a, t1))
+        row('CBM + IGM statistics P2', 2 * nb, lambda: F2.fusion_stats(a, b, tok))
+        a3, b3 = a[:, :h2 // 2].contiguous(), b[:, :h2 // 2].contiguous()
+        row('Add (rgb + ir) half a T2', 3 * nb // 2, lambda: ops.add(a3, b3))
+        x5 = torch.randn(bs, size // 32, size // 32, 4 * c2, device=dev)
+        row('SPP 5/9/13 pools -> concat buffer', x5.numel() * 4 * 5, lambda: ops.spp_pool(x5))
+        img = torch.rand(bs, size, size, 3, device=dev)
+        was = model.Enhance.training
+        model.Enhance.eval()                     # (eval: the timing must not move the BatchNorm running statistics)
+        row('CEM forward (3 reads + 1 write of x; 24-ch intermediates are the excess)', 4 * img.numel() * 4, lambda: model.Enhance(img))
+        model.Enhance.train(was)
+        mi = torch.cat([torch.zeros(c2, device=dev), torch.ones(c2, device=dev)])
+        g1, b1 = torch.ones(c2, device=dev), torch.zeros(c2, device=dev)
+        o = torch.empty_like(a)
+        from mmidet_hip import lib
+        st = torch.cuda.current_stream().cuda_stream
+        rows = a.numel() // c2
+        row('BatchNorm normalise + SiLU (T2-size)', 2 * nb, lambda: lib.bn_act_fwd(a.data_ptr(), c2, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                                                                                     None, 0, o.data_ptr(), c2, rows, c2, 1, st))
+        nbw = lib.bn_act_bwd_workspace(rows, c2)
+        ws = torch.zeros(nbw, dtype=torch.uint8, device=dev)
+        dg, db = torch.empty(c2, device=dev), torch.empty(c2, device=dev)
+        row('BatchNorm backward, both passes (T2-size; 4 reads + 1 write)', 5 * nb, lambda: lib.bn_act_bwd(
+            a.data_ptr(), c2, b.data_ptr(), c2, None, 0, c2, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(), ws.data_ptr(), nbw, o.data_ptr(), c2,
+            dg.data_ptr(), db.data_ptr(), None, None, rows, c2, 1, 0, st))
+    return out
+
+
 def host_cores():
     """CPU share of this process: affinity, capped by the cgroup quota (a 1-GPU box grants 16 cores)."""
     n = os.cpu_count() or 1
@@ -520,6 +579,11 @@ def main():
                        'loss_finite': v[1], 'last_loss': v[2], 'arithmetic': what[k]} for k, v in split.items()}}
         if pcie is not None:
             out['pcie_inclusive'] = pcie
+        if not args.no_roofline and args.workload != 's_add':
+            try:
+                out['hbm_bound_ops'] = hbm_ops(model, bs, size, dev)
+            except Exception as e:          # (an optional report never fails the run)
+                out['hbm_bound_ops'] = {'error': repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.workload)
         sys.stdout.flush()
