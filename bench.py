@@ -295,11 +295,16 @@ def main():
                          'products (each product exact).  Both: full-depth gradients as the fp32 path over four seeds. '
                          'bf16x3: two terms, three products (GEMM 4.5e-6, full-depth gradients ~1e-2)')
     ap.add_argument('--no-split-probe', action='store_true', help='skip the extra split-bf16 measurement after the timed region')
+    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
+                    help='activation storage.  f32 (default, the headline: fp32 parity).  bf16: OPT-IN AMP-like mode (SURVEY.md §8 f-4) -- '
+                         'bf16 maps in HBM, one bf16 MFMA product per element pair, fp32 accumulation / weights / statistics / loss')
     ap.add_argument('--h2d', action='store_true', help='also time the step fed from HOST memory through the pinned, double-buffered '
                                                        'feeder (mmidet_hip.feed): the PCIe-inclusive rate, reported beside `value`')
     ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     args = ap.parse_args()
+    if args.storage == 'bf16':          # (the roofline pass and the split-bf16 probe describe the fp32 kernels)
+        args.no_roofline = args.no_split_probe = True
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves.  This parent never touches the GPU
@@ -354,6 +359,7 @@ def main():
     nc = cfg['nc']
     bs = args.batch or WORKLOADS[args.workload][5]
     model = Model(cfg).to(dev)
+    model.storage = args.storage
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = args.dropout
@@ -515,7 +521,7 @@ def main():
             'metric': 'paired RGB+IR img/s (train step, %dx%d %s two-stream)' % (size, size, 'yolov5x' if args.workload == 'x_1280' else 'yolov5s' if args.workload.startswith('s_') else 'yolov5l'), 'value': round(value, 3),
             'unit': 'paired img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'bf16x9': 'f32 storage/accumulation, exact products as 9 bf16 MFMAs of a 3-term split',
+            'dtype': 'bf16 storage + bf16 MFMA, fp32 accumulation / weights / BatchNorm statistics / loss (opt-in, NOT the parity headline)' if args.storage == 'bf16' else {'fp32': 'f32', 'bf16x9': 'f32 storage/accumulation, exact products as 9 bf16 MFMAs of a 3-term split',
                       'bf16x6': 'f32 storage/accumulation, products as 6 bf16 MFMAs of a 3-term split',
                       'bf16x3': 'f32 storage/accumulation, products as 3 bf16 MFMAs of a 2-term split'}[args.gemm],
             'data': 'synthetic',

@@ -356,6 +356,36 @@ int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float
             int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes, float* out, int* nout,
             void* stream);
 
+/* ---- bf16 storage (the reference trains under torch.cuda.amp, train.py:706,784,796-801) ---------
+ * Opt-in second numeric mode of the conv family and its glue: activations and activation gradients are bf16 in HBM (NHWC,
+ * same row-stride convention, counted in ELEMENTS), weights / weight gradients / BatchNorm parameters and statistics stay
+ * fp32; every product is one bf16 MFMA with fp32 accumulation, statistics are taken from the fp32 accumulators.  bf16 has
+ * fp32's exponent range, so no loss scaling is involved (GradScaler exists for fp16).  Same semantics and workspace rules
+ * as the fp32 entry points of the same name; channel counts and row strides must be multiples of 4. */
+int mmi_conv_fwd_row_blocks_bf16(const mmi_conv_desc* d);
+size_t mmi_conv_fwd_workspace_bf16(const mmi_conv_desc* d);
+/* bn != NULL: training Conv, statistics finished in the launch (as mmi_conv_bn_fwd); bias != NULL: Detect-style bias */
+int mmi_conv_fwd_bf16(const void* x, const float* w, const float* bias, void* y, float* stat_partials, const mmi_bn_stats* bn,
+                      void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+/* dx = conv_transpose(dy, w) [+ skip] (skip: 1x1 stride-1 layers, the Bottleneck shortcut gradient) */
+int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, const mmi_conv_desc* d, void* stream);
+/* dw, dbias fp32; workspace as mmi_conv_wgrad */
+int mmi_conv_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                        const mmi_conv_desc* d, void* stream);
+int mmi_bn_act_fwd_split_bf16(const void* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                              const void* residual, int ldr, void* out, int ldo, void* out1, int ldo1, int split, int64_t rows,
+                              int C, int act, void* stream);
+int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split,
+                        const float* mean_invstd, const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
+                        void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C,
+                        int act, int frozen, void* stream);
+int mmi_cast_f32_bf16(const float* in, int ldi, void* out, int ldo, int64_t rows, int C, void* stream);   /* round to nearest even */
+int mmi_cast_bf16_f32(const void* in, int ldi, float* out, int ldo, int64_t rows, int C, void* stream);
+int mmi_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C, void* stream);
+int mmi_copy2d_bf16(const void* in, int ldi, void* out, int ldo, int64_t rows, int C, void* stream);
+int mmi_upsample2x_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int mmi_upsample2x_bwd_bf16(const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+
 /* ---- data-parallel communication (one process per GPU, RCCL over xGMI) ---------------------------------------------
  * Replaces DistributedDataParallel's gradient all-reduce and initial parameter broadcast (train.py:683-686 of the
  * reference; SURVEY.md §8e: pure data parallelism, one all-reduce of all trainable gradients per optimizer step).  RCCL is

@@ -95,6 +95,29 @@ template <int V>
 struct Vec {
   float v[V];
 };
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// bf16 storage: the streaming kernels are templated on the activation type T (float or __bf16); the
+// arithmetic, the statistics and the parameters are fp32 either way
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const __bf16* p) {
+  Vec<V> r;
+  if (V == 4) {
+    const bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+    r.v[0] = (float)t[0]; r.v[1 % V] = (float)t[1]; r.v[2 % V] = (float)t[2]; r.v[3 % V] = (float)t[3];
+  } else {
+    r.v[0] = (float)p[0];
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(__bf16* p, const Vec<V>& r) {
+  if (V == 4) {
+    bf16x4_t t = {(__bf16)r.v[0], (__bf16)r.v[1 % V], (__bf16)r.v[2 % V], (__bf16)r.v[3 % V]};
+    *reinterpret_cast<bf16x4_t*>(p) = t;
+  } else {
+    p[0] = (__bf16)r.v[0];
+  }
+}
 template <int V>
 __device__ __forceinline__ Vec<V> ldv(const float* p) {
   Vec<V> r;
@@ -121,11 +144,11 @@ __device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
 // element; otherwise the general index arithmetic is used.
 // Output channels [0, split) go to out (row stride ldo), channels [split, C) to out1 (ldo1): C3's merged cv1|cv2 conv hands
 // its first half to the bottleneck chain and writes the second half straight into the concat buffer (split = C: one output).
-template <int V, bool FIXED>
-__global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ mi,
+template <typename T, int V, bool FIXED>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ mi,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                  const float* __restrict__ res, int ldr, float* __restrict__ out, int ldo,
-                                  float* __restrict__ out1, int ldo1, int split, int64_t rows, int C, int act) {
+                                  const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
+                                  T* __restrict__ out1, int ldo1, int split, int64_t rows, int C, int act) {
   const int cv = C / V;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,11 +156,11 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ y, int ldy, const fl
     const int64_t r0 = e0 / cv, dr = stride / cv;
     const int c = (int)(e0 - r0 * cv) * V;
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
-    const float* py = y + r0 * ldy + c;
-    const float* pr = res != nullptr ? res + r0 * ldr + c : nullptr;
+    const T* py = y + r0 * ldy + c;
+    const T* pr = res != nullptr ? res + r0 * ldr + c : nullptr;
     const bool hi = c >= split;
     const int ldo_ = hi ? ldo1 : ldo;
-    float* po = (hi ? out1 + (c - split) : out + c) + r0 * ldo_;
+    T* po = (hi ? out1 + (c - split) : out + c) + r0 * ldo_;
     const int64_t sy = dr * ldy, sr = dr * ldr, so = dr * ldo_;
 #pragma unroll 2
     for (int64_t r = r0; r < rows; r += dr, py += sy, po += so) {
@@ -182,9 +205,9 @@ struct BnSplitOut {
   float* dgamma1;
   float* dbeta1;
 };
-template <int V>
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
-                                     const float* __restrict__ dout1, int ldd1, int split,
+template <typename T, int V>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                                     const T* __restrict__ dout1, int ldd1, int split,
                                      const float* __restrict__ mi, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ partials, int64_t rows, int C,
                                      int act, int64_t rows_per_part, StatFold fold, BnSplitOut o) {
@@ -202,7 +225,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, int ldy, const
   if (c < C) {
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
     const bool hi = c >= split;
-    const float* pd = hi ? dout1 + (c - split) : dout + c;
+    const T* pd = hi ? dout1 + (c - split) : dout + c;
     const int ldd_ = hi ? ldd1 : ldd;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(pd + r * ldd_);
@@ -306,11 +329,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   }
 }
 
-template <int V, bool FIXED>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dout, int ldd,
-                                    const float* __restrict__ dout1, int ldd1, int split,
+template <typename T, int V, bool FIXED>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                                    const T* __restrict__ dout1, int ldd1, int split,
                                     const float* __restrict__ mi, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, BnSplitOut gs, float* __restrict__ dy, int lddy, int64_t rows, int C,
+                                    const float* __restrict__ beta, BnSplitOut gs, T* __restrict__ dy, int lddy, int64_t rows, int C,
                                     int act, int frozen) {
   const int cv = C / V;
   const float inv_rows = 1.0f / (float)rows;
@@ -323,9 +346,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, int ldy, const 
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
                  dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
     const int ldd_ = hi ? ldd1 : ldd;
-    const float* py = y + r0 * ldy + c;
-    const float* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
-    float* po = dy + r0 * lddy + c;
+    const T* py = y + r0 * ldy + c;
+    const T* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
+    T* po = dy + r0 * lddy + c;
     const int64_t sy = dr * ldy, sd = dr * ldd_, so = dr * lddy;
 #pragma unroll 2
     for (int64_t r = r0; r < rows; r += dr, py += sy, pd += sd, po += so) {
@@ -404,12 +427,12 @@ inline int ew_grid(int64_t rows, int cv, bool* fixed) {
   *fixed = ((int64_t)b * 256) % cv == 0;
   return b;
 }
-inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs, uintptr_t mask = 15) {
   if (C % 4) return false;
   for (int l : lds)
     if (l % 4) return false;
   for (const void* p : ptrs)
-    if (p && ((uintptr_t)p & 15)) return false;
+    if (p && ((uintptr_t)p & mask)) return false;
   return true;
 }
 
@@ -444,18 +467,21 @@ extern "C" int mmi_bn_eval_stats(const float* running_mean, const float* running
   return MMI_OK;
 }
 
-extern "C" int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
-                                    const float* residual, int ldr, float* out, int ldo, float* out1, int ldo1, int split,
-                                    int64_t rows, int C, int act, void* stream) {
+namespace {
+template <typename T>
+int bn_act_fwd_impl(const T* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta, const T* residual, int ldr,
+                    T* out, int ldo, T* out1, int ldo1, int split, int64_t rows, int C, int act, void* stream) {
   MMI_CHECK_ARG(y && mean_invstd && gamma && beta && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
   MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (out1 && split % 4 == 0 && ldo1 >= C - split)), "mmi_bn_act_fwd: bad channel split");
   MMI_CHECK_ARG(ldy >= C && ldo >= split && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
   hipStream_t s = (hipStream_t)stream;
-  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0, split < C ? ldo1 : 0}, {y, out, residual, mean_invstd, gamma, beta, split < C ? out1 : nullptr});
+  const uintptr_t am = 4 * sizeof(T) - 1;
+  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0, split < C ? ldo1 : 0}, {y, out, residual, split < C ? out1 : nullptr}, am) &&
+                   vec_ok(C, {}, {mean_invstd, gamma, beta});
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_FWD(V_, F_) \
-  hipLaunchKernelGGL((bn_act_fwd_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta, residual, \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta, residual, \
                      ldr, out, ldo, out1, ldo1, split, rows, C, act)
   if (vec && fixed) LAUNCH_FWD(4, true);
   else if (vec) LAUNCH_FWD(4, false);
@@ -464,6 +490,20 @@ extern "C" int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_i
 #undef LAUNCH_FWD
   MMI_CHECK_LAUNCH("mmi_bn_act_fwd");
   return MMI_OK;
+}
+}  // namespace
+
+extern "C" int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                                    const float* residual, int ldr, float* out, int ldo, float* out1, int ldo1, int split,
+                                    int64_t rows, int C, int act, void* stream) {
+  return bn_act_fwd_impl<float>(y, ldy, mean_invstd, gamma, beta, residual, ldr, out, ldo, out1, ldo1, split, rows, C, act, stream);
+}
+
+extern "C" int mmi_bn_act_fwd_split_bf16(const void* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
+                                         const void* residual, int ldr, void* out, int ldo, void* out1, int ldo1, int split,
+                                         int64_t rows, int C, int act, void* stream) {
+  return bn_act_fwd_impl<__bf16>((const __bf16*)y, ldy, mean_invstd, gamma, beta, (const __bf16*)residual, ldr, (__bf16*)out, ldo,
+                                 (__bf16*)out1, ldo1, split, rows, C, act, stream);
 }
 
 extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
@@ -491,27 +531,27 @@ extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout,
     hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel, dim3(1, nparts), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp);
   else if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp, nofold, noout);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp, nofold, noout);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_reduce");
   return MMI_OK;
 }
 
 namespace {
-int launch_apply(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
-                 const float* mean_invstd, const float* gamma, const float* beta, const BnSplitOut& gs, float* dy, int lddy,
+template <typename T>
+int launch_apply(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split,
+                 const float* mean_invstd, const float* gamma, const float* beta, const BnSplitOut& gs, T* dy, int lddy,
                  int64_t rows, int C, int act, int frozen, hipStream_t s) {
   const bool two = split < C;
-  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0},
-                          {y, dout, dy, mean_invstd, gamma, beta, gs.dgamma0, gs.dbeta0, two ? dout1 : nullptr, two ? gs.dgamma1 : nullptr,
-                           two ? gs.dbeta1 : nullptr});
+  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0}, {y, dout, dy, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) &&
+                   vec_ok(C, {}, {mean_invstd, gamma, beta, gs.dgamma0, gs.dbeta0, two ? gs.dgamma1 : nullptr, two ? gs.dbeta1 : nullptr});
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_APPLY(V_, F_) \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
                      gamma, beta, gs, dy, lddy, rows, C, act, frozen)
   if (vec && fixed) LAUNCH_APPLY(4, true);
   else if (vec) LAUNCH_APPLY(4, false);
@@ -533,7 +573,7 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
   const BnSplitOut gs{dgamma, dbeta, nullptr, nullptr};
-  return launch_apply(y, ldy, dout, ldd, nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  return launch_apply<float>(y, ldy, dout, ldd, nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
 }
 
 // One-call BatchNorm(+activation) backward: reduce (whose last-arriving workgroups write dgamma / dbeta) + apply = two
@@ -545,10 +585,11 @@ extern "C" size_t mmi_bn_act_bwd_workspace(int64_t rows, int C) {
   return (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int) + ((size_t)nparts + ngroups) * 2 * C * sizeof(float);
 }
 
-extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
-                              const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
-                              size_t workspace_bytes, float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
-                              float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
+namespace {
+template <typename T>
+int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split, const float* mean_invstd,
+                    const float* gamma, const float* beta, void* workspace, size_t workspace_bytes, T* dy, int lddy, float* dgamma,
+                    float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
   MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && workspace && dy && dgamma && dbeta && rows > 0 && C > 0,
                 "mmi_bn_act_bwd: bad arguments");
   MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (dout1 && dgamma1 && dbeta1 && split % 4 == 0 && ldd1 >= C - split && C > 8)),
@@ -561,24 +602,43 @@ extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ld
   const BnSplitOut gs{dgamma, dbeta, dgamma1, dbeta1};
   const int nct = cdiv(C, 64), G = stat_group_size(nparts), ngroups = cdiv(nparts, G);
   static const bool fold_off = getenv("MMIDET_BN_FOLD") != nullptr && atoi(getenv("MMIDET_BN_FOLD")) == 0;  // (A/B switch)
-  if (split == C && (C <= 8 || fold_off || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS)) {  // the CEM's 3-channel map: one thread per row, separate fold
-    if (int e = mmi_bn_act_bwd_reduce(y, ldy, dout, ldd, mean_invstd, gamma, beta, partials, rows, C, act, stream)) return e;
-    MMI_CHECK_ARG(split == C, "mmi_bn_act_bwd: channel split unsupported for this shape");
+  const bool is_f32 = sizeof(T) == 4;
+  if (is_f32 && split == C && (C <= 8 || fold_off || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS)) {  // the CEM's 3-channel map: one thread per row, separate fold
+    if (int e = mmi_bn_act_bwd_reduce((const float*)y, ldy, (const float*)dout, ldd, mean_invstd, gamma, beta, partials, rows, C, act, stream)) return e;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, dgamma, dbeta, 1);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(finalize)");
   } else {
+    MMI_CHECK_ARG(ngroups * nct + nct <= MMI_STAT_MAX_COUNTERS, "mmi_bn_act_bwd: too many column tiles");
     StatFold f{partials, partials + (size_t)nparts * 2 * C, (int*)workspace, nparts, C, nct, G};
     const dim3 grid(nct, nparts);
     const bool two = split < C;
-    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, mean_invstd, gamma, beta, two ? dout1 : nullptr}))
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) && vec_ok(C, {}, {mean_invstd, gamma, beta}))
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
                          partials, rows, C, act, rpp, f, gs);
     else
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
                          partials, rows, C, act, rpp, f, gs);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(reduce)");
   }
-  return launch_apply(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  return launch_apply<T>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+}
+}  // namespace
+
+extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
+                              const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
+                              size_t workspace_bytes, float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
+                              float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
+  return bn_act_bwd_impl<float>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, workspace, workspace_bytes, dy, lddy,
+                                dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen, stream);
+}
+
+extern "C" int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split,
+                                   const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
+                                   size_t workspace_bytes, void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
+                                   float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
+  return bn_act_bwd_impl<__bf16>((const __bf16*)y, ldy, (const __bf16*)dout, ldd, (const __bf16*)dout1, ldd1, split, mean_invstd, gamma,
+                                 beta, workspace, workspace_bytes, (__bf16*)dy, lddy, dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen,
+                                 stream);
 }
 
 extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {

@@ -277,14 +277,19 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 #define MMI_UNI_OCC 3
 #endif
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC == 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
-  constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
-  constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;                // highest total order of the products kept
-  // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (36 or 52 floats: both make
+  // PREC = 4 (bf16 STORAGE): the activation operand A and the output C live in HBM as bf16 (the weights stay
+  // fp32 master copies, rounded when a tile is staged), one bf16 MFMA product per element pair, fp32 accumulation, fp32
+  // BatchNorm statistics taken from the accumulators.  Same tile machinery as the split forms with a single plane.
+  constexpr bool BF = PREC == 4;
+  static_assert(!BF || !UNI, "bf16 storage uses the cursor loaders");
+  constexpr int NP = PREC == 0 || BF ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
+  constexpr int OL = BF ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);          // highest total order of the products kept
+  // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (20, 36 or 52 floats: each makes
   // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
-  constexpr int RSF = PREC >= 2 ? 52 : LDS_PAD;
+  constexpr int RSF = BF ? 20 : (PREC >= 2 ? 52 : LDS_PAD);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * RSF;
@@ -392,6 +397,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[RA];
+    bf16x4 rab[BF ? RA : 1];  // bf16 storage: the A operand arrives as 4 bf16 per load
     constexpr int NB = DGRAD ? KB_IT : RB;
     f32x4 rb[NB];
 
@@ -478,7 +484,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
       }
       int64_t pix = 0;
       const bool ok = (ca.tap < ntaps) & src_pixel<DGRAD>(p, rows[i], tp.kh0 + tp.khs * ca.ti, tp.kw0 + tp.kws * ca.tj, pix);
-      ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
+      if constexpr (BF)
+        rab[i] = *reinterpret_cast<const bf16x4*>(ok ? reinterpret_cast<const char*>(p.A) + (pix * p.lda + ca.c) * 2
+                                                     : reinterpret_cast<const char*>(ZERO_SRC));
+      else
+        ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
     };
     auto load_b_row = [&](int i) {
       if (!DGRAD) {
@@ -548,7 +558,8 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
           bf16x4 tm[NP];
-          split_bf16<NP>(ra[i], tm);
+          if constexpr (BF) tm[0] = rab[i];
+          else split_bf16<NP>(ra[i], tm);
           __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPP * i) * RSF);
 #pragma unroll
           for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
@@ -777,10 +788,13 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && PREC < 2
             } else if (p.epi == MMI_EPI_GELU_GRAD) {
               v *= gelu_grad_f(p.aux[ao]);
             } else if (p.epi == MMI_EPI_ACCUMULATE) {
-              v += p.aux[ao];
+              v += BF ? (float)reinterpret_cast<const __bf16*>(p.aux)[ao] : p.aux[ao];
             }
           }
-          if (cok && row < Mc) p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
+          if (cok && row < Mc) {
+            if constexpr (BF) reinterpret_cast<__bf16*>(p.C)[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = (__bf16)v;
+            else p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
+          }
         }
       }
       if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
@@ -864,11 +878,13 @@ struct WgradP {
 // a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
 // resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
 template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
-__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && PREC < 2) ? 3 : 2)) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC == 4)) ? 3 : 2)) void wgrad_kernel(WgradP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
-  constexpr int NP = PREC == 0 ? 1 : (PREC == 3 ? 3 : PREC + 1);
-  constexpr int OL = PREC == 3 ? 2 * (NP - 1) : NP - 1;
+  constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
+  static_assert(!BF || !TAB, "bf16 storage uses the cursor loaders");
+  constexpr int NP = PREC == 0 || BF ? 1 : (PREC == 3 ? 3 : PREC + 1);
+  constexpr int OL = BF ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
@@ -920,6 +936,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[ITA], rb[ITB];
+  bf16x4 rab[BF ? ITA : 1], rbb[BF ? ITB : 1];
   const int howo = p.Ho * p.Wo;
   const bool want_bias = (p.OUTB != nullptr) && (nt == 0);  // uniform: the first N-tile of each (M-tile, split)
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -1035,7 +1052,11 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     const int pix = k0cur + akr + RPA * i;
     if (VEC) {  // branch-free: an invalid lane reads the base address and is zeroed
       const bool ok = (pix < kend) & (am < p.Cout);
-      ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.DY + (int64_t)pix * p.ldy + am : ZERO_SRC);
+      if constexpr (BF)
+        rab[i] = *reinterpret_cast<const bf16x4*>(ok ? reinterpret_cast<const char*>(p.DY) + ((int64_t)pix * p.ldy + am) * 2
+                                                     : reinterpret_cast<const char*>(ZERO_SRC));
+      else
+        ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.DY + (int64_t)pix * p.ldy + am : ZERO_SRC);
     } else {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pix < kend) {
@@ -1067,8 +1088,13 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     if (VEC) {
       const int ih = ih0 + b_kh[0], iw = iw0 + b_kw[0];
       const bool ok = (pix < kend) & b_ok[0] & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
-      rb[i] = *reinterpret_cast<const f32x4*>(
-          ok ? p.X + (((int64_t)cimg[i] * p.H + ih) * p.W + iw) * p.ldx + b_ci[0] : ZERO_SRC);
+      if constexpr (BF)
+        rbb[i] = *reinterpret_cast<const bf16x4*>(
+            ok ? reinterpret_cast<const char*>(p.X) + ((((int64_t)cimg[i] * p.H + ih) * p.W + iw) * p.ldx + b_ci[0]) * 2
+               : reinterpret_cast<const char*>(ZERO_SRC));
+      else
+        rb[i] = *reinterpret_cast<const f32x4*>(
+            ok ? p.X + (((int64_t)cimg[i] * p.H + ih) * p.W + iw) * p.ldx + b_ci[0] : ZERO_SRC);
     } else {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pix < kend) {
@@ -1097,16 +1123,25 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 #pragma unroll
       for (int i = 0; i < ITA; ++i) {
         bf16x4 tm[NP];
-        split_bf16<NP>(ra[i], tm);
+        if constexpr (BF) tm[0] = rab[i];
+        else split_bf16<NP>(ra[i], tm);
         char* dst = ab + (akr + RPA * i) * A_RSB + (t % VA) * 8;
 #pragma unroll
         for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * A_RSB) = tm[k];
-        if (want_bias) bsum += ra[i];
+        if (want_bias) {
+          if constexpr (BF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[e] += (float)rab[i][e];
+          } else {
+            bsum += ra[i];
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < ITB; ++i) {
         bf16x4 tm[NP];
-        split_bf16<NP>(rb[i], tm);
+        if constexpr (BF) tm[0] = rbb[i];
+        else split_bf16<NP>(rb[i], tm);
         char* dst = bb + (bkr + RPB * i) * B_RSB + (t % VB) * 8;
 #pragma unroll
         for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
@@ -1923,7 +1958,7 @@ extern "C" int mmi_conv_wgrad_table_build(void* table, const mmi_conv_desc* d, v
 
 namespace {
 int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                    const void* table, const mmi_conv_desc* d, void* stream);
+                    const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io = false);
 }
 extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
@@ -1936,10 +1971,10 @@ extern "C" int mmi_conv_wgrad_tab(const float* dy, const float* x, float* dw, fl
 
 namespace {
 int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                    const void* table, const mmi_conv_desc* d, void* stream) {
+                    const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io) {
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
-  if (mmi_smallconv_supported(d) && dbias == nullptr) {
+  if (mmi_smallconv_supported(d) && dbias == nullptr && !bf16_io) {
     if (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d)) {
       mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d));
       return MMI_ERR_WORKSPACE;
@@ -1947,7 +1982,8 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
     return mmi_smallconv_wgrad(dy, x, dw, (char*)workspace + WG_COUNTER_BYTES, d, (hipStream_t)stream);   // (never the counter block)
   }
   const WgPlan g = wgrad_plan(d);
-  MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
+  MMI_CHECK_ARG(!bf16_io || g.vec, "mmi_conv_wgrad_bf16: channel counts and row strides must be multiples of 4");
+  MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & (bf16_io ? 7 : 15)) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
   const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;
   const int64_t slab = wsize + d->Cout;  // weight gradient + bias-gradient tail
   if (g.splits > 1 && (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + (size_t)g.splits * slab * sizeof(float) ||
@@ -1981,7 +2017,7 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   hipStream_t s = (hipStream_t)stream;
   // pixel-table loaders (wgrad_kernel<..., TAB>): tap mask in 32 bits, 31-bit byte offsets into x
   bool tab = false;
-  if (g.vec && g_uniform_loaders && g_gemm_prec == 0 && d->KH * d->KW <= 32) {
+  if (g.vec && g_uniform_loaders && g_gemm_prec == 0 && d->KH * d->KW <= 32 && !bf16_io) {
     const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
     const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4;
     if (x_bytes < (1LL << 31)) {
@@ -1992,7 +2028,14 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   }
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
-  if (g.vec && g_gemm_prec >= 1) {
+  if (bf16_io) {
+#define LAUNCHWB(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4>), grid, block, 0, s, p)
+    if (g.bm == 128 && g.bn == 128) LAUNCHWB(128, 128);
+    else if (g.bm == 128) LAUNCHWB(128, 64);
+    else if (g.bn == 128) LAUNCHWB(64, 128);
+    else LAUNCHWB(64, 64);
+#undef LAUNCHWB
+  } else if (g.vec && g_gemm_prec >= 1) {
 #define LAUNCHW3(BM_, BN_)                                                                              \
   do {                                                                                                  \
     if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p);  \
@@ -2028,3 +2071,116 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   return MMI_OK;
 }
 }  // namespace
+
+// ---- bf16 storage: activations and activation gradients are bf16 in HBM, weights / weight gradients /
+// BatchNorm statistics fp32; one bf16 MFMA product per element pair with fp32 accumulation (igemm_kernel<..., PREC = 4>).
+// One workgroup per tile (no stream-K: these launches are HBM-bound, not wave-quantisation-bound).
+namespace {
+template <bool DGRAD, bool EPI>
+int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who) {
+  p.zero = zero_src();
+  if (p.zero == nullptr) {
+    mmi_set_error("%s: cannot resolve the zero-source symbol", who);
+    return MMI_ERR_LAUNCH;
+  }
+  p.mtiles = f.mtiles;
+  p.ntiles = f.ntiles;
+  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
+  if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  MMI_CHECK_LAUNCH(who);
+  return MMI_OK;
+}
+FwdPlan fwd_plan_bf16(const mmi_conv_desc* d) { return plan_tiles((int64_t)d->N * d->Ho * d->Wo, d->Cout); }
+FwdPlan dgrad_plan_bf16(const mmi_conv_desc* d) {
+  const bool par = dgrad_par(d);
+  const int64_t mrows = par ? (int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (int64_t)d->N * d->H * d->W;
+  return plan_tiles(mrows, d->Cin);
+}
+}  // namespace
+
+extern "C" int mmi_conv_fwd_row_blocks_bf16(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_fwd_row_blocks_bf16") != MMI_OK) return MMI_ERR_ARG;
+  return fwd_plan_bf16(d).mtiles;
+}
+
+extern "C" size_t mmi_conv_fwd_workspace_bf16(const mmi_conv_desc* d) {
+  if (check_desc(d, "mmi_conv_fwd_workspace_bf16") != MMI_OK) return 0;
+  return WS_HEADER_BYTES + bn_l1_bytes(fwd_plan_bf16(d), d->Cout);
+}
+
+extern "C" int mmi_conv_fwd_bf16(const void* x, const float* w, const float* bias, void* y, float* stat_partials,
+                                 const mmi_bn_stats* bn, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                                 void* stream) {
+  const char* who = "mmi_conv_fwd_bf16";
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(x && w && y, "%s: null pointer", who);
+  MMI_CHECK_ARG(!(bias && stat_partials), "%s: bias and BN statistics are mutually exclusive", who);
+  MMI_CHECK_ARG(fwd_vec(d) && d->ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0 && ((uintptr_t)w & 15) == 0,
+                "%s: channel counts / row strides must be multiples of 4 and the operands aligned", who);
+  IgemmP p{};
+  p.A = (const float*)x; p.B = w; p.C = (float*)y; p.bias = bias; p.stat_part = stat_partials;
+  p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
+  const FwdPlan f = fwd_plan_bf16(d);
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  bool fold = false;
+  if (bn != nullptr) {
+    MMI_CHECK_ARG(stat_partials && bn->mean_invstd, "%s: BN statistics need the partials buffer and mean_invstd", who);
+    fold = bn_fold_fits(f) && (bn->num_batches_tracked2 == nullptr || bn->num_batches_tracked2 == bn->num_batches_tracked + 1);
+    if (fold) {
+      if (workspace == nullptr || workspace_bytes < WS_HEADER_BYTES + bn_l1_bytes(f, d->Cout) || ((uintptr_t)workspace & 15)) {
+        mmi_set_error("%s: needs a 16-byte aligned zero-initialised workspace of %zu bytes (got %zu)", who,
+                      WS_HEADER_BYTES + bn_l1_bytes(f, d->Cout), workspace_bytes);
+        return MMI_ERR_WORKSPACE;
+      }
+      p.bn_fold = StatFold{stat_partials, (float*)((char*)workspace + WS_HEADER_BYTES), (int*)((char*)workspace + SK_COUNTER_BYTES),
+                           f.mtiles, d->Cout, f.ntiles, stat_group_size(f.mtiles)};
+      p.bn_mi = bn->mean_invstd;
+      p.bn_rmean = bn->running_mean; p.bn_rvar = bn->running_var;
+      p.bn_nbt = bn->num_batches_tracked;
+      p.bn_nnbt = bn->num_batches_tracked == nullptr ? 0 : (bn->num_batches_tracked2 != nullptr ? 2 : 1);
+      p.bn_eps = bn->eps; p.bn_momentum = bn->momentum;
+      p.bn_inv_rows = 1.0 / (double)rows; p.bn_unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+    }
+  }
+  if (int e = launch_igemm_bf16<false, false>(p, f, (hipStream_t)stream, who)) return e;
+  if (bn != nullptr && !fold) {
+    if (int e = mmi_bn_finalize(stat_partials, f.mtiles, rows, d->Cout, bn->eps, bn->momentum, bn->running_mean, bn->running_var,
+                                bn->num_batches_tracked, bn->mean_invstd, stream)) return e;
+    if (bn->num_batches_tracked2 != nullptr)
+      if (int e = mmi_i64_increment(bn->num_batches_tracked2, stream)) return e;
+  }
+  return MMI_OK;
+}
+
+// dx = conv_transpose(dy, w) [+ skip]: dy, dx, skip bf16 (skip: 1x1 stride-1 layers only, row stride ldskip; may be NULL)
+extern "C" int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, const mmi_conv_desc* d,
+                                   void* stream) {
+  const char* who = "mmi_conv_dgrad_bf16";
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(dy && w && dx, "%s: null pointer", who);
+  MMI_CHECK_ARG(dgrad_vec(d) && d->ldx % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 7) == 0 && ((uintptr_t)w & 15) == 0,
+                "%s: channel counts / row strides must be multiples of 4 and the operands aligned", who);
+  IgemmP p{};
+  p.A = (const float*)dy; p.B = w; p.C = (float*)dx;
+  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
+  p.par = dgrad_par(d) ? 1 : 0;
+  if (skip != nullptr) {
+    MMI_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && ldskip >= d->Cin && skip != dx,
+                  "%s: the skip accumulation exists for 1x1 stride-1 layers", who);
+    p.epi = MMI_EPI_ACCUMULATE; p.aux = (const float*)skip; p.ldaux = ldskip;
+    return launch_igemm_bf16<true, true>(p, dgrad_plan_bf16(d), (hipStream_t)stream, who);
+  }
+  return launch_igemm_bf16<true, false>(p, dgrad_plan_bf16(d), (hipStream_t)stream, who);
+}
+
+extern "C" int mmi_conv_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                   const mmi_conv_desc* d, void* stream) {
+  return conv_wgrad_impl((const float*)dy, (const float*)x, dw, dbias, workspace, workspace_bytes, nullptr, d, stream, true);
+}
+

@@ -423,8 +423,9 @@ class _PoolTokens(Function):
 
     @staticmethod
     def forward(ctx, rgb, ir):
-        rgb, ld0 = rows_of(rgb)
-        ir, ld1 = rows_of(ir)
+        ctx.src = rgb.dtype                                  # (bf16 storage: the pooling kernels read fp32 for now)
+        rgb, ld0 = rows_of(ops.raw_cast(rgb, torch.float32))
+        ir, ld1 = rows_of(ops.raw_cast(ir, torch.float32))
         n, h, w, c = rgb.shape
         tok = torch.empty((n, 128, c), dtype=rgb.dtype, device=rgb.device)
         s = _stream()
@@ -442,7 +443,7 @@ class _PoolTokens(Function):
         d1 = torch.empty_like(d0)
         lib.avgpool8_bwd(g.data_ptr(), 128 * c, c, d0.data_ptr(), c, n, h, w, c, s)
         lib.avgpool8_bwd(g.data_ptr() + 4 * 64 * c, 128 * c, c, d1.data_ptr(), c, n, h, w, c, s)
-        return d0, d1
+        return ops.raw_cast(d0, ctx.src), ops.raw_cast(d1, ctx.src)
 
 
 def pool_tokens(rgb, ir):
@@ -484,21 +485,23 @@ class _UpsampleAdd(Function):
 
     @staticmethod
     def forward(ctx, x, tok):
-        x, ldx = rows_of(x)
+        ctx.src = x.dtype
+        x, ldx = rows_of(ops.raw_cast(x, torch.float32))
         tok = tok.contiguous()
         n, h, w, c = x.shape
         out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.upsample_add_fwd(x.data_ptr(), ldx, tok.data_ptr(), 64 * c, c, out.data_ptr(), c, n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
-        return out
+        return ops.raw_cast(out, ctx.src)
 
     @staticmethod
     def backward(ctx, g):
         n, h, w, c = ctx.shape
-        g, ldg = rows_of(g)
+        g0 = g
+        g, ldg = rows_of(ops.raw_cast(g, torch.float32))
         dtok = torch.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
         lib.upsample_add_bwd(g.data_ptr(), ldg, dtok.data_ptr(), 64 * c, c, n, h, w, c, _stream())
-        return g, dtok
+        return ops.raw_cast(g0, ctx.src), dtok
 
 
 def upsample_add(x, tok):
@@ -552,8 +555,8 @@ def separation_loss(m_rgb, m_ir, m_rgb_hi, m_ir_hi):
 
 def fusion_stats(in_rgb, in_ir, tok):
     """(SSIMloss, Entropy_loss, ContrastiveValue) as a 3-vector, no gradient."""
-    a, lda = rows_of(in_rgb)
-    b, ldb = rows_of(in_ir)
+    a, lda = rows_of(ops.raw_cast(in_rgb, torch.float32))
+    b, ldb = rows_of(ops.raw_cast(in_ir, torch.float32))
     tok = tok.contiguous()
     n, h, w, c = a.shape
     ws = scratch(lib.fusion_stats_workspace() // 4 + 4, a.device, slot=2)

@@ -114,6 +114,20 @@ _SIGS = {
     'mmi_separation_loss': (c_int, [P, P, P, P, c_int, P, P]),
     'mmi_fusion_stats_workspace': (c_size_t, []),
     'mmi_fusion_stats': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'mmi_conv_fwd_row_blocks_bf16': (c_int, [POINTER(ConvDesc)]),
+    'mmi_conv_fwd_workspace_bf16': (c_size_t, [POINTER(ConvDesc)]),
+    'mmi_conv_fwd_bf16': (c_int, [P, P, P, P, P, POINTER(BnStats), P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad_bf16': (c_int, [P, P, P, P, c_int, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad_bf16': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_bn_act_fwd_split_bf16': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int64, c_int, c_int, P]),
+    'mmi_bn_act_bwd_bf16': (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P, P, c_size_t, P, c_int, P, P, P, P, c_int64, c_int,
+                                    c_int, c_int, P]),
+    'mmi_cast_f32_bf16': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_cast_bf16_f32': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_add_bf16': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_copy2d_bf16': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_upsample2x_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample2x_bwd_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_comm_available': (c_int, []),
     'mmi_comm_unique_id': (c_int, [P]),
     'mmi_comm_init': (c_int, [c_int, c_int, P]),
@@ -130,7 +144,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

@@ -80,7 +80,7 @@ def conv_dgrad(dy, w, dx, d, s):
 def rows_of(t):
     """Return (tensor, ld): `tensor` is `t` (or a compacted copy) viewed as rows x C with unit channel stride and a
     uniform row stride ld."""
-    assert t.dtype == torch.float32 and t.is_cuda, 'mmidet_hip ops need fp32 tensors on the MI355X'
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda, 'mmidet_hip ops need fp32 (or bf16-storage) tensors on the MI355X'
     C = t.shape[-1]
     if t.is_contiguous():          # the common case
         return t, C
@@ -204,21 +204,27 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
     nbytes = _wgrad_ws.get(k)
     if nbytes is None:
         nbytes = _wgrad_ws[k] = lib.conv_wgrad_workspace(d)
-    tab = wgrad_table(d, w.device)
+    bf = dy.dtype == BF16
+    assert x.dtype == dy.dtype, 'wgrad operands must share the storage type'
+    tab = None if bf else wgrad_table(d, w.device)
     tabp = tab.data_ptr() if tab is not None else None
+
+    def launch(wsp, st):
+        if bf:
+            lib.conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, wsp, nbytes, d, st)
+        else:
+            lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, wsp, nbytes, tabp, d, st)
     if overlap:
         main, side = torch.cuda.current_stream(), _side_stream(w.device)
         ws = zeroed_scratch(nbytes, w.device, side.cuda_stream, tag='w') if nbytes else None
         side.wait_stream(main)
-        lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
-                           tabp, d, side.cuda_stream)
+        launch(ws.data_ptr() if ws is not None else None, side.cuda_stream)
         if DEFER_JOIN:
             _pending.append((dy, x))
             _pending_sides[side.cuda_stream] = side
     else:
         ws = zeroed_scratch(nbytes, w.device, tag='w') if nbytes else None
-        lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbp, ws.data_ptr() if ws is not None else None, nbytes,
-                           tabp, d, _stream())
+        launch(ws.data_ptr() if ws is not None else None, _stream())
     return (dw, db) if want_bias else dw
 
 
@@ -248,6 +254,36 @@ def join_pending():
         for side in _side_streams.values():      # (per-layer-join mode included: every wgrad stream, once)
             cur.wait_stream(side)
         _retired.clear()
+
+
+BF16 = torch.bfloat16
+
+
+def raw_cast(t, dtype):
+    """fp32 <-> bf16 copy of an NHWC / rows tensor (no autograd): the storage-mode boundary (csrc/bf16_ops.hip)."""
+    if t.dtype == dtype:
+        return t
+    t, ld = rows_of(t)
+    out = torch.empty(tuple(t.shape), dtype=dtype, device=t.device)
+    c = t.shape[-1]
+    fn = lib.cast_f32_bf16 if dtype == BF16 else lib.cast_bf16_f32
+    fn(t.data_ptr(), ld, out.data_ptr(), c, _nrows(t), c, _stream())
+    return out
+
+
+class _Cast(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return raw_cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return raw_cast(g, ctx.src), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
 
 class Dest:
@@ -291,24 +327,71 @@ def bn_bwd_ws(rows, c):
 
 def _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, nbt2, s):
     """conv + BatchNorm statistics (training: folded inside the conv launch) -> mean_invstd (2*cout)."""
-    mi = torch.empty(2 * cout, dtype=x.dtype, device=x.device)
-    nb, nrb = fwd_plan(d)
+    mi = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+    bf = x.dtype == BF16
+    nb, nrb = fwd_plan_bf16(d) if bf else fwd_plan(d)
     ws = zeroed_scratch(nb, x.device, s) if nb else None
+    wsp = ws.data_ptr() if nb else None
     if training:
         part = scratch((nrb + 64) * 2 * cout, x.device)     # + MMI_BN_FOLD_ROWS spare rows (the CEM's separate fold)
         bn = lib.BnStats(eps, momentum, rmean.data_ptr(), rvar.data_ptr(), nbt.data_ptr() if nbt is not None else None,
                          nbt2.data_ptr() if nbt2 is not None else None, mi.data_ptr())
-        lib.conv_bn_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), part.data_ptr(), bn, ws.data_ptr() if nb else None, nb, d, s)
+        if bf:
+            lib.conv_fwd_bf16(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), part.data_ptr(), bn, wsp, nb, d, s)
+        else:
+            lib.conv_bn_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), part.data_ptr(), bn, wsp, nb, d, s)
     else:
-        lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, ws.data_ptr() if nb else None, nb, d, s)
+        if bf:
+            lib.conv_fwd_bf16(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, None, wsp, nb, d, s)
+        else:
+            lib.conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, wsp, nb, d, s)
         lib.bn_eval_stats(rmean.data_ptr(), rvar.data_ptr(), cout, eps, mi.data_ptr(), s)
     return mi
+
+
+def fwd_plan_bf16(d):
+    k = ('bf16',) + _desc_key(d)
+    v = _plan_cache.get(k)
+    if v is None:
+        v = _plan_cache[k] = (lib.conv_fwd_workspace_bf16(d), lib.conv_fwd_row_blocks_bf16(d))
+    return v
+
+
+def _bn_act_fwd(y, ldy, mi, gamma, beta, residual, ldr, out, ldo, out1, ldo1, split, rows, c, act, s):
+    fn = lib.bn_act_fwd_split_bf16 if y.dtype == BF16 else lib.bn_act_fwd_split
+    fn(y.data_ptr(), ldy, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(), residual.data_ptr() if residual is not None else None,
+       ldr, out.data_ptr(), ldo, out1.data_ptr() if out1 is not None else None, ldo1, split, rows, c, act, s)
+
+
+def _bn_act_bwd(y, ldy, dout, ldd, dout1, ldd1, split, mi, gamma, beta, dy, dgs, rows, c, act, frozen, s):
+    nbw = bn_bwd_ws(rows, c)
+    ws = zeroed_scratch(nbw, y.device, s, tag='bn')
+    fn = lib.bn_act_bwd_bf16 if y.dtype == BF16 else lib.bn_act_bwd
+    fn(y.data_ptr(), ldy, dout.data_ptr(), ldd, dout1.data_ptr() if dout1 is not None else None, ldd1, split, mi.data_ptr(),
+       gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), nbw, dy.data_ptr(), c, dgs[0].data_ptr(), dgs[1].data_ptr(),
+       dgs[2].data_ptr() if dgs[2] is not None else None, dgs[3].data_ptr() if dgs[3] is not None else None, rows, c, act, frozen, s)
+
+
+def _conv_dgrad_any(dy, w, dx, dd, s, skip=None, lds=0):
+    if dy.dtype == BF16:
+        lib.conv_dgrad_bf16(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), skip.data_ptr() if skip is not None else None, lds, dd, s)
+    else:
+        assert skip is None
+        conv_dgrad(dy, w, dx, dd, s)
 
 
 def _dgrad_accumulate(dy, w, dx, d, dd, skip, s):
     """dx = conv_transpose(dy, w) + skip.  1x1 stride-1 layers add in the GEMM epilogue (MMI_EPI_ACCUMULATE); others in a pass
     of their own."""
     skip, lds = rows_of(skip)
+    if dy.dtype == BF16:
+        skip = raw_cast(skip, BF16)
+        if d.KH == 1 and d.stride == 1 and lds % 4 == 0:
+            _conv_dgrad_any(dy, w, dx, dd, s, skip, lds)
+        else:
+            _conv_dgrad_any(dy, w, dx, dd, s)
+            lib.add_bf16(dx.data_ptr(), d.Cin, skip.data_ptr(), lds, dx.data_ptr(), d.Cin, _nrows(dx), d.Cin, s)
+        return
     if d.KH == 1 and d.stride == 1 and d.Cin % 4 == 0 and d.Cout % 4 == 0 and dd.ldy % 4 == 0 and lds % 4 == 0:
         nb = lib.conv_dgrad_workspace(dd)
         ws = zeroed_scratch(nb, dy.device, s) if nb else None
@@ -338,12 +421,11 @@ class _ConvBnAct(Function):
         mi = _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, None, s)
         out = _dest_view(dest, y.shape) if dest is not None else torch.empty_like(y)
         ldo = rows_of(out)[1]
-        assert out.stride(-1) == 1 and rows_of(out)[0] is out, 'the destination slice must be a strided NHWC view'
+        assert out.stride(-1) == 1 and rows_of(out)[0] is out and out.dtype == y.dtype, 'the destination slice must be a strided NHWC view'
+        ldr = 0
         if residual is not None:
-            residual, ldr = rows_of(residual)
-        lib.bn_act_fwd(y.data_ptr(), cout, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                       residual.data_ptr() if residual is not None else None, ldr if residual is not None else 0,
-                       out.data_ptr(), ldo, rows, cout, act, s)
+            residual, ldr = rows_of(raw_cast(residual, y.dtype))
+        _bn_act_fwd(y, cout, mi, gamma, beta, residual, ldr, out, ldo, None, 0, cout, rows, cout, act, s)
         ctx.save_for_backward(x, w, y, mi, gamma, beta)
         ctx.cfg = (d, act, training, residual is not None, skip)
         return (out, x_in) if skip else out
@@ -352,18 +434,15 @@ class _ConvBnAct(Function):
     def backward(ctx, dout, dskip=None):
         x, w, y, mi, gamma, beta = ctx.saved_tensors
         d, act, training, has_res, skip = ctx.cfg
-        dout, ldd = rows_of(dout)
+        dout, ldd = rows_of(raw_cast(dout, y.dtype))
         cout = d.Cout
         rows = d.N * d.Ho * d.Wo
         s = _stream()
-        nbw = bn_bwd_ws(rows, cout)
-        ws = zeroed_scratch(nbw, x.device, s, tag='bn')
         dy = torch.empty_like(y)
         dgamma = grad_like(gamma)
         dbeta = grad_like(beta)
-        lib.bn_act_bwd(y.data_ptr(), cout, dout.data_ptr(), ldd, None, 0, cout, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                       ws.data_ptr(), nbw, dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), None, None, rows, cout, act,
-                       0 if training else 1, s)
+        _bn_act_bwd(y, cout, dout, ldd, None, 0, cout, mi, gamma, beta, dy, (dgamma, dbeta, None, None), rows, cout, act,
+                    0 if training else 1, s)
         dx = None
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
@@ -373,7 +452,7 @@ class _ConvBnAct(Function):
             if skip and dskip is not None:
                 _dgrad_accumulate(dy, w, dx, d, dd, dskip, s)
             else:
-                conv_dgrad(dy, w, dx, dd, s)
+                _conv_dgrad_any(dy, w, dx, dd, s)
         if both:
             _join_side(x.device)
         return dx, dw, dgamma, dbeta, None, None, None, (dout if has_res else None), None, None, None, None, None, None, None
@@ -413,8 +492,8 @@ class _DualConvBnAct(Function):
         a = torch.empty((d.N, d.Ho, d.Wo, c_), dtype=x.dtype, device=x.device)
         b = _dest_view(dest, a.shape)
         ldb = rows_of(b)[1]
-        lib.bn_act_fwd_split(y.data_ptr(), cout, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(), None, 0, a.data_ptr(), c_,
-                             b.data_ptr(), ldb, c_, rows, cout, act, s)
+        assert b.dtype == y.dtype
+        _bn_act_fwd(y, cout, mi, g1, b1, None, 0, a, c_, b, ldb, c_, rows, cout, act, s)
         ctx.save_for_backward(x, w1, w2, y, mi, g1, b1, g2, b2)
         ctx.cfg = (d, act, training, c_)
         return a, b
@@ -424,15 +503,11 @@ class _DualConvBnAct(Function):
         x, w1, w2, y, mi, g1, b1, g2, b2 = ctx.saved_tensors
         d, act, training, c_ = ctx.cfg
         cout, rows, s = 2 * c_, d.N * d.Ho * d.Wo, _stream()
-        da, lda = rows_of(da)
-        db, ldb = rows_of(db)
-        nbw = bn_bwd_ws(rows, cout)
-        ws = zeroed_scratch(nbw, x.device, s, tag='bn')
+        da, lda = rows_of(raw_cast(da, y.dtype))
+        db, ldb = rows_of(raw_cast(db, y.dtype))
         dy = torch.empty_like(y)
         dg1, dbt1, dg2, dbt2 = grad_like(g1), grad_like(b1), grad_like(g2), grad_like(b2)
-        lib.bn_act_bwd(y.data_ptr(), cout, da.data_ptr(), lda, db.data_ptr(), ldb, c_, mi.data_ptr(), g1.data_ptr(), b1.data_ptr(),
-                       ws.data_ptr(), nbw, dy.data_ptr(), cout, dg1.data_ptr(), dbt1.data_ptr(), dg2.data_ptr(), dbt2.data_ptr(),
-                       rows, cout, act, 0 if training else 1, s)
+        _bn_act_bwd(y, cout, da, lda, db, ldb, c_, mi, g1, b1, dy, (dg1, dbt1, dg2, dbt2), rows, cout, act, 0 if training else 1, s)
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0]
         d1 = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, c_, 1, 1, 1, 0, d.ldx, cout)
         dw1 = _wgrad(dy[..., :c_], cout, x, d.ldx, w1, d1, overlap=both) if ctx.needs_input_grad[1] else None
@@ -441,7 +516,7 @@ class _DualConvBnAct(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.Cin, cout)
-            conv_dgrad(dy, w1, dx, dd, s)
+            _conv_dgrad_any(dy, w1, dx, dd, s)
         if both:
             _join_side(x.device)
         return dx, dw1, dw2, dg1, dbt1, dg2, dbt2, None, None, None, None, None, None, None, None, None
@@ -459,7 +534,7 @@ class _CatAlias(Function):
     def forward(ctx, a, b, holder):
         cat = holder.t
         ca = a.shape[-1]
-        assert a.data_ptr() == cat.data_ptr() and b.data_ptr() == cat.data_ptr() + 4 * ca and ca + b.shape[-1] == cat.shape[-1], \
+        assert a.data_ptr() == cat.data_ptr() and b.data_ptr() == cat.data_ptr() + cat.element_size() * ca and ca + b.shape[-1] == cat.shape[-1], \
             'cat_alias: the inputs are not the channel halves of the buffer'
         ctx.ca = ca
         return cat
@@ -520,7 +595,15 @@ class _ConvBias(Function):
         d = _desc(xs, cout, k, stride, ldx, cout)
         oshape = (*x.shape[:-1], cout) if w.dim() == 2 else (d.N, d.Ho, d.Wo, cout)
         y = torch.empty(oshape, dtype=x.dtype, device=x.device)
-        conv_fwd(x, w, bias, y, None, d, _stream())
+        if x.dtype == BF16:
+            # bf16 storage: the map is bf16, this layer's OUTPUT (a Detect head: what the loss reads) is handed on as fp32
+            nb = fwd_plan_bf16(d)[0]
+            ws = zeroed_scratch(nb, x.device, _stream())
+            lib.conv_fwd_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), None, None,
+                              ws.data_ptr(), nb, d, _stream())
+            y = raw_cast(y, torch.float32)
+        else:
+            conv_fwd(x, w, bias, y, None, d, _stream())
         ctx.save_for_backward(x, w)
         ctx.bias = bias            # (only its address is needed in backward: where the bias gradient goes)
         ctx.cfg = (d, bias is not None)
@@ -530,7 +613,7 @@ class _ConvBias(Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         d, has_bias = ctx.cfg
-        dy, lddy = rows_of(dy)
+        dy, lddy = rows_of(raw_cast(dy, x.dtype))
         s = _stream()
         dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, lddy)
         dx = None
@@ -545,7 +628,7 @@ class _ConvBias(Function):
                 dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
-            conv_dgrad(dy, w, dx, dd, s)
+            _conv_dgrad_any(dy, w, dx, dd, s)
         if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
             db = grad_like(ctx.bias)
@@ -628,7 +711,8 @@ class _Add(Function):
         b, ldb = rows_of(b)
         out = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
         c = a.shape[-1]
-        lib.add(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), c, _nrows(a), c, _stream())
+        assert a.dtype == b.dtype
+        (lib.add_bf16 if a.dtype == BF16 else lib.add)(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), c, _nrows(a), c, _stream())
         return out
 
     @staticmethod
@@ -649,10 +733,12 @@ class _Concat(Function):
         out = torch.empty((*xs[0].shape[:-1], ctot), dtype=xs[0].dtype, device=xs[0].device)
         off = 0
         s = _stream()
+        es = out.element_size()
+        cp = lib.copy2d_bf16 if out.dtype == BF16 else lib.copy2d
         for x in xs:
-            x, ld = rows_of(x)
+            x, ld = rows_of(raw_cast(x, out.dtype))
             c = x.shape[-1]
-            lib.copy2d(x.data_ptr(), ld, out.data_ptr() + 4 * off, ctot, _nrows(x), c, s)
+            cp(x.data_ptr(), ld, out.data_ptr() + es * off, ctot, _nrows(x), c, s)
             off += c
         ctx.sizes = [x.shape[-1] for x in xs]
         return out
@@ -678,7 +764,7 @@ class _Upsample2x(Function):
             x = x.contiguous()
         n, h, w, c = x.shape
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
-        lib.upsample2x(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
+        (lib.upsample2x_bf16 if x.dtype == BF16 else lib.upsample2x)(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
         return y
 
@@ -687,7 +773,7 @@ class _Upsample2x(Function):
         n, h, w, c = ctx.shape
         g = g.contiguous()
         dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
-        lib.upsample2x_bwd(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
+        (lib.upsample2x_bwd_bf16 if g.dtype == BF16 else lib.upsample2x_bwd)(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
         return dx
 
 
@@ -700,22 +786,23 @@ class _SppPool(Function):
 
     @staticmethod
     def forward(ctx, x):
-        x, ld = rows_of(x)
+        ctx.src = x.dtype
+        x, ld = rows_of(raw_cast(x, torch.float32))      # (bf16 storage: a P5-sized map; the pooling kernels are fp32)
         n, h, w, c = x.shape
         out = torch.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
         lib.spp_pool_fwd(x.data_ptr(), ld, out.data_ptr(), 4 * c, n, h, w, c, _stream())
         ctx.save_for_backward(x)
-        return out
+        return raw_cast(out, ctx.src)
 
     @staticmethod
     def backward(ctx, g):
         x, = ctx.saved_tensors
         x, ld = rows_of(x)
-        g, ldg = rows_of(g)
+        g, ldg = rows_of(raw_cast(g, torch.float32))
         n, h, w, c = x.shape
         dx = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.spp_pool_bwd(x.data_ptr(), ld, g.data_ptr(), ldg, dx.data_ptr(), c, n, h, w, c, _stream())
-        return dx
+        return raw_cast(dx, ctx.src)
 
 
 def spp_pool(x):

@@ -107,6 +107,9 @@ class Model(nn.Module):
         initialize_weights(self)
         self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = self.Combine_loss = torch.zeros(0)
         self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
+        # activation storage of the backbone / neck: 'f32' (parity mode, the default) or 'bf16' (opt-in AMP-like mode, SURVEY.md
+        # §8 f-4: bf16 maps in HBM, fp32 weights / statistics / loss; the images, the CEM and Focus' first conv stay fp32)
+        self.storage = os.environ.get('MMIDET_STORAGE', 'f32')
         self._plan_lanes()
 
     def _plan_lanes(self):
@@ -199,6 +202,7 @@ class Model(nn.Module):
                 x2.record_stream(ir)
             done = {}
         x = self.Enhance(x)                                        # CEM on the RGB stream only
+        bf16 = getattr(self, 'storage', 'f32') == 'bf16'
         y = []
         prev = x
         for m in self.model:
@@ -216,6 +220,8 @@ class Model(nn.Module):
                 ctx.__enter__()
             if m.f == -4:
                 x = m(x2)
+                if bf16:
+                    x = ops.cast(x, torch.bfloat16)
             elif isinstance(m, GPT1_fourier):
                 in_rgb, in_ir = x[0], x[1]
                 x, pt = m(x)
@@ -224,6 +230,8 @@ class Model(nn.Module):
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
                 x = m(x)
+                if bf16 and m.i == 0:
+                    x = ops.cast(x, torch.bfloat16)          # behind the RGB stem (Focus): everything downstream is bf16
             if lanes:
                 ev = torch.cuda.Event()
                 ev.record(st_)
