@@ -584,6 +584,9 @@ class _ConvBias(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride):
+        ctx.src = x.dtype
+        if x.dtype == BF16 and (w.shape[0] % 4 != 0 or x.shape[-1] % 4 != 0):
+            x = raw_cast(x, torch.float32)       # (a Detect head has 3*(nc+5) = 33 columns: the bf16 kernels want multiples of 4)
         x, ldx = rows_of(x)
         w = _ohwi(w)
         if w.dim() == 2:
@@ -636,6 +639,8 @@ class _ConvBias(Function):
             lib.colsum(dy.data_ptr(), lddy, rows, d.Cout, part.data_ptr(), db.data_ptr(), s)
         if both:
             _join_side(x.device)
+        if dx is not None and dx.dtype != ctx.src:
+            dx = raw_cast(dx, ctx.src)
         return dx, dw, db, None
 
 
