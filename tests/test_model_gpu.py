@@ -351,6 +351,21 @@ def test_yolov5l_640_gradients_against_the_fp64_arbiter():
                'e_hip_median': sorted(r[1] for r in rows)[len(rows) // 2], 'e_cpu_median': sorted(r[2] for r in rows)[len(rows) // 2],
                'e_hip_max': max(r[1] for r in rows), 'e_cpu_max': max(r[2] for r in rows),
                'worst': [(round(r[0], 2), '%.2e' % r[1], '%.2e' % r[2], r[3]) for r in sorted(rows)[-5:]]}
+    # ---- the opt-in bf16-storage mode on the same step, characterised against the same fp64 truth (reported, loosely bounded)
+    del pg, lg
+    m.zero_grad(set_to_none=True)
+    m.storage = 'bf16'
+    pb, cb = m(xd[:, :3], xd[:, 3:])
+    lb, ib = ComputeLoss(m)(pb, targets.to(dev()), cb.reshape(-1))
+    lb.backward()
+    torch.cuda.synchronize()
+    m.storage = 'f32'
+    eb = sorted(float((p.grad.detach().double().cpu() - g64[n]).norm()) / float(g64[n].norm())
+                for n, p in m.named_parameters() if p.grad is not None and float(g64[n].norm()) >= 1e-12)
+    summary['bf16_storage'] = {'pred_rel_err_vs_fp64': [rel_err(pb[i], p64[i]) for i in range(3)],
+                               'loss_rel_err_vs_fp64': abs(float(lb) - float(l64)) / abs(float(l64)),
+                               'grad_e_median': eb[len(eb) // 2], 'grad_e_p90': eb[int(0.9 * len(eb))], 'grad_e_max': eb[-1]}
+    assert summary['bf16_storage']['loss_rel_err_vs_fp64'] < 5e-2 and summary['bf16_storage']['grad_e_median'] < 0.5, summary['bf16_storage']
     out = os.path.join(here, '..', 'gpurun_out')
     if os.path.isdir(out):
         with open(os.path.join(out, 'fp64_arbiter_summary.json'), 'w') as f:
