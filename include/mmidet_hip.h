@@ -367,20 +367,15 @@ size_t mmi_conv_fwd_workspace_bf16(const mmi_conv_desc* d);
 /* bn != NULL: training Conv, statistics finished in the launch (as mmi_conv_bn_fwd); bias != NULL: Detect-style bias */
 int mmi_conv_fwd_bf16(const void* x, const float* w, const float* bias, void* y, float* stat_partials, const mmi_bn_stats* bn,
                       void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
-/* dx = conv_transpose(dy, w) [+ skip] (skip: 1x1 stride-1 layers, the Bottleneck shortcut gradient).  dy is bf16 (it comes out
- * of the BatchNorm backward and feeds the GEMMs only); dx and skip are fp32 when dx_f32 != 0 -- what the storage mode uses:
- * gradients that travel BETWEEN layers keep fp32, because the next BatchNorm backward projects their per-channel common mode
- * out and 8 mantissa bits before that projection leave 40-60 % gradient error -- or bf16 (dx_f32 = 0). */
-int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, int dx_f32, const mmi_conv_desc* d,
-                        void* stream);
+/* dx = conv_transpose(dy, w) [+ skip] (skip: 1x1 stride-1 layers, the Bottleneck shortcut gradient) */
+int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, const mmi_conv_desc* d, void* stream);
 /* dw, dbias fp32; workspace as mmi_conv_wgrad */
 int mmi_conv_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                         const mmi_conv_desc* d, void* stream);
 int mmi_bn_act_fwd_split_bf16(const void* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
                               const void* residual, int ldr, void* out, int ldo, void* out1, int ldo1, int split, int64_t rows,
                               int C, int act, void* stream);
-/* y, dy bf16; dout / dout1 fp32 when dout_f32 != 0 (see mmi_conv_dgrad_bf16), else bf16 */
-int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split, int dout_f32,
+int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split,
                         const float* mean_invstd, const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
                         void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C,
                         int act, int frozen, void* stream);

@@ -205,9 +205,9 @@ struct BnSplitOut {
   float* dgamma1;
   float* dbeta1;
 };
-template <typename T, typename TG, int V>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const TG* __restrict__ dout, int ldd,
-                                     const TG* __restrict__ dout1, int ldd1, int split,
+template <typename T, int V>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                                     const T* __restrict__ dout1, int ldd1, int split,
                                      const float* __restrict__ mi, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ partials, int64_t rows, int C,
                                      int act, int64_t rows_per_part, StatFold fold, BnSplitOut o) {
@@ -225,7 +225,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const TG*
   if (c < C) {
     const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
     const bool hi = c >= split;
-    const TG* pd = hi ? dout1 + (c - split) : dout + c;
+    const T* pd = hi ? dout1 + (c - split) : dout + c;
     const int ldd_ = hi ? ldd1 : ldd;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(pd + r * ldd_);
@@ -329,9 +329,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
   }
 }
 
-template <typename T, typename TG, int V, bool FIXED>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const TG* __restrict__ dout, int ldd,
-                                    const TG* __restrict__ dout1, int ldd1, int split,
+template <typename T, int V, bool FIXED>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
+                                    const T* __restrict__ dout1, int ldd1, int split,
                                     const float* __restrict__ mi, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, BnSplitOut gs, T* __restrict__ dy, int lddy, int64_t rows, int C,
                                     int act, int frozen) {
@@ -347,7 +347,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const TG* 
                  dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
     const int ldd_ = hi ? ldd1 : ldd;
     const T* py = y + r0 * ldy + c;
-    const TG* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
+    const T* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
     T* po = dy + r0 * lddy + c;
     const int64_t sy = dr * ldy, sd = dr * ldd_, so = dr * lddy;
 #pragma unroll 2
@@ -531,28 +531,27 @@ extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout,
     hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel, dim3(1, nparts), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp);
   else if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp, nofold, noout);
   else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp, nofold, noout);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_reduce");
   return MMI_OK;
 }
 
 namespace {
-template <typename T, typename TG>
-int launch_apply(const T* y, int ldy, const TG* dout, int ldd, const TG* dout1, int ldd1, int split,
+template <typename T>
+int launch_apply(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split,
                  const float* mean_invstd, const float* gamma, const float* beta, const BnSplitOut& gs, T* dy, int lddy,
                  int64_t rows, int C, int act, int frozen, hipStream_t s) {
   const bool two = split < C;
-  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0}, {y, dy}, 4 * sizeof(T) - 1) &&
-                   vec_ok(C, {}, {dout, two ? dout1 : nullptr}, 4 * sizeof(TG) - 1) &&
+  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0}, {y, dout, dy, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) &&
                    vec_ok(C, {}, {mean_invstd, gamma, beta, gs.dgamma0, gs.dbeta0, two ? gs.dgamma1 : nullptr, two ? gs.dbeta1 : nullptr});
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_APPLY(V_, F_) \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TG, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
                      gamma, beta, gs, dy, lddy, rows, C, act, frozen)
   if (vec && fixed) LAUNCH_APPLY(4, true);
   else if (vec) LAUNCH_APPLY(4, false);
@@ -574,7 +573,7 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
   const BnSplitOut gs{dgamma, dbeta, nullptr, nullptr};
-  return launch_apply<float, float>(y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  return launch_apply<float>(y, ldy, dout, ldd, nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
 }
 
 // One-call BatchNorm(+activation) backward: reduce (whose last-arriving workgroups write dgamma / dbeta) + apply = two
@@ -587,8 +586,8 @@ extern "C" size_t mmi_bn_act_bwd_workspace(int64_t rows, int C) {
 }
 
 namespace {
-template <typename T, typename TG>
-int bn_act_bwd_impl(const T* y, int ldy, const TG* dout, int ldd, const TG* dout1, int ldd1, int split, const float* mean_invstd,
+template <typename T>
+int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split, const float* mean_invstd,
                     const float* gamma, const float* beta, void* workspace, size_t workspace_bytes, T* dy, int lddy, float* dgamma,
                     float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
   MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && workspace && dy && dgamma && dbeta && rows > 0 && C > 0,
@@ -613,16 +612,15 @@ int bn_act_bwd_impl(const T* y, int ldy, const TG* dout, int ldd, const TG* dout
     StatFold f{partials, partials + (size_t)nparts * 2 * C, (int*)workspace, nparts, C, nct, G};
     const dim3 grid(nct, nparts);
     const bool two = split < C;
-    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y}, 4 * sizeof(T) - 1) && vec_ok(C, {}, {dout, two ? dout1 : nullptr}, 4 * sizeof(TG) - 1) &&
-        vec_ok(C, {}, {mean_invstd, gamma, beta}))
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, TG, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) && vec_ok(C, {}, {mean_invstd, gamma, beta}))
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
                          partials, rows, C, act, rpp, f, gs);
     else
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, TG, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
                          partials, rows, C, act, rpp, f, gs);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(reduce)");
   }
-  return launch_apply<T, TG>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  return launch_apply<T>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
 }
 }  // namespace
 
@@ -630,22 +628,17 @@ extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ld
                               const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
                               size_t workspace_bytes, float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
                               float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
-  return bn_act_bwd_impl<float, float>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, workspace, workspace_bytes, dy, lddy,
+  return bn_act_bwd_impl<float>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, workspace, workspace_bytes, dy, lddy,
                                 dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen, stream);
 }
 
-// y and dy bf16; the incoming gradient(s) dout fp32 (dout_f32 != 0: the storage mode's default, see mmi_conv_dgrad_bf16) or bf16
 extern "C" int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split,
-                                   int dout_f32, const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
+                                   const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
                                    size_t workspace_bytes, void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
                                    float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
-  if (dout_f32)
-    return bn_act_bwd_impl<__bf16, float>((const __bf16*)y, ldy, (const float*)dout, ldd, (const float*)dout1, ldd1, split, mean_invstd,
-                                          gamma, beta, workspace, workspace_bytes, (__bf16*)dy, lddy, dgamma, dbeta, dgamma1, dbeta1, rows,
-                                          C, act, frozen, stream);
-  return bn_act_bwd_impl<__bf16, __bf16>((const __bf16*)y, ldy, (const __bf16*)dout, ldd, (const __bf16*)dout1, ldd1, split, mean_invstd,
-                                         gamma, beta, workspace, workspace_bytes, (__bf16*)dy, lddy, dgamma, dbeta, dgamma1, dbeta1, rows,
-                                         C, act, frozen, stream);
+  return bn_act_bwd_impl<__bf16>((const __bf16*)y, ldy, (const __bf16*)dout, ldd, (const __bf16*)dout1, ldd1, split, mean_invstd, gamma,
+                                 beta, workspace, workspace_bytes, (__bf16*)dy, lddy, dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen,
+                                 stream);
 }
 
 extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {

@@ -88,8 +88,6 @@ struct IgemmP {
   int bn_nnbt;
   float bn_eps, bn_momentum;
   double bn_inv_rows, bn_unbias;  // 1 / rows, rows / (rows - 1)
-  int c_f32;  // bf16 storage (PREC = 4): the OUTPUT (and the accumulate epilogue's aux) is fp32 all the same -- activation
-              // gradients travel between layers in fp32, see mmi_conv_dgrad_bf16
 };
 
 // Tap enumeration of the K axis: k = tap * Kc + c, tap = ti * ntw + tj, (kh, kw) = (kh0 + khs*ti, kw0 + kws*tj).
@@ -790,11 +788,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
             } else if (p.epi == MMI_EPI_GELU_GRAD) {
               v *= gelu_grad_f(p.aux[ao]);
             } else if (p.epi == MMI_EPI_ACCUMULATE) {
-              v += (BF && !p.c_f32) ? (float)reinterpret_cast<const __bf16*>(p.aux)[ao] : p.aux[ao];
+              v += BF ? (float)reinterpret_cast<const __bf16*>(p.aux)[ao] : p.aux[ao];
             }
           }
           if (cok && row < Mc) {
-            if (BF && !p.c_f32) reinterpret_cast<__bf16*>(p.C)[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = (__bf16)v;
+            if constexpr (BF) reinterpret_cast<__bf16*>(p.C)[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = (__bf16)v;
             else p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
           }
         }
@@ -2158,21 +2156,15 @@ extern "C" int mmi_conv_fwd_bf16(const void* x, const float* w, const float* bia
   return MMI_OK;
 }
 
-// dx = conv_transpose(dy, w) [+ skip]: dy is bf16 (the BatchNorm backward's output, which feeds the GEMMs only); dx and skip are
-// fp32 when dx_f32 != 0 -- the default of the storage mode: a gradient that travels on to the previous layer's BatchNorm
-// backward still carries its per-channel common-mode part, which that backward projects out; rounding it to 8 bits before the
-// projection leaves noise of the order of the result (measured: 40-60 % per-tensor gradient error with bf16 gradients, 0.5 %
-// with the same bf16 activations and fp32 gradients; profiles/r02_bf16_gradient_diag*.txt) -- or bf16 (dx_f32 = 0).
-// skip: 1x1 stride-1 layers only, row stride ldskip; may be NULL.
-extern "C" int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, int dx_f32,
-                                   const mmi_conv_desc* d, void* stream) {
+// dx = conv_transpose(dy, w) [+ skip]: dy, dx, skip bf16 (skip: 1x1 stride-1 layers only, row stride ldskip; may be NULL)
+extern "C" int mmi_conv_dgrad_bf16(const void* dy, const float* w, void* dx, const void* skip, int ldskip, const mmi_conv_desc* d,
+                                   void* stream) {
   const char* who = "mmi_conv_dgrad_bf16";
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(dy && w && dx, "%s: null pointer", who);
   MMI_CHECK_ARG(dgrad_vec(d) && d->ldx % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 7) == 0 && ((uintptr_t)w & 15) == 0,
                 "%s: channel counts / row strides must be multiples of 4 and the operands aligned", who);
   IgemmP p{};
-  p.c_f32 = dx_f32 ? 1 : 0;
   p.A = (const float*)dy; p.B = w; p.C = (float*)dx;
   p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;

@@ -423,7 +423,7 @@ class _PoolTokens(Function):
 
     @staticmethod
     def forward(ctx, rgb, ir):
-        ctx.src = ops.storage_dtype(rgb)                     # (bf16 storage: the pooling kernels read fp32 for now)
+        ctx.src = rgb.dtype                                  # (bf16 storage: the pooling kernels read fp32 for now)
         rgb, ld0 = rows_of(ops.raw_cast(rgb, torch.float32))
         ir, ld1 = rows_of(ops.raw_cast(ir, torch.float32))
         n, h, w, c = rgb.shape
@@ -443,7 +443,7 @@ class _PoolTokens(Function):
         d1 = torch.empty_like(d0)
         lib.avgpool8_bwd(g.data_ptr(), 128 * c, c, d0.data_ptr(), c, n, h, w, c, s)
         lib.avgpool8_bwd(g.data_ptr() + 4 * 64 * c, 128 * c, c, d1.data_ptr(), c, n, h, w, c, s)
-        return ops.raw_cast(d0, ops.grad_dtype(ctx.src)), ops.raw_cast(d1, ops.grad_dtype(ctx.src))
+        return ops.raw_cast(d0, ctx.src), ops.raw_cast(d1, ctx.src)
 
 
 def pool_tokens(rgb, ir):
@@ -485,14 +485,14 @@ class _UpsampleAdd(Function):
 
     @staticmethod
     def forward(ctx, x, tok):
-        ctx.src = ops.storage_dtype(x)
+        ctx.src = x.dtype
         x, ldx = rows_of(ops.raw_cast(x, torch.float32))
         tok = tok.contiguous()
         n, h, w, c = x.shape
         out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.upsample_add_fwd(x.data_ptr(), ldx, tok.data_ptr(), 64 * c, c, out.data_ptr(), c, n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
-        return ops.wrap(ops.raw_cast(out, ctx.src))
+        return ops.raw_cast(out, ctx.src)
 
     @staticmethod
     def backward(ctx, g):
@@ -501,7 +501,7 @@ class _UpsampleAdd(Function):
         g, ldg = rows_of(ops.raw_cast(g, torch.float32))
         dtok = torch.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
         lib.upsample_add_bwd(g.data_ptr(), ldg, dtok.data_ptr(), 64 * c, c, n, h, w, c, _stream())
-        return ops.raw_cast(g0, ops.grad_dtype(ctx.src)), dtok
+        return ops.raw_cast(g0, ctx.src), dtok
 
 
 def upsample_add(x, tok):

@@ -117,11 +117,11 @@ _SIGS = {
     'mmi_conv_fwd_row_blocks_bf16': (c_int, [POINTER(ConvDesc)]),
     'mmi_conv_fwd_workspace_bf16': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_fwd_bf16': (c_int, [P, P, P, P, P, POINTER(BnStats), P, c_size_t, POINTER(ConvDesc), P]),
-    'mmi_conv_dgrad_bf16': (c_int, [P, P, P, P, c_int, c_int, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad_bf16': (c_int, [P, P, P, P, c_int, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_bf16': (c_int, [P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_bn_act_fwd_split_bf16': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, P, c_int, c_int, c_int64, c_int, c_int, P]),
-    'mmi_bn_act_bwd_bf16': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P, c_int, P, P, P, P, c_int64,
-                                    c_int, c_int, c_int, P]),
+    'mmi_bn_act_bwd_bf16': (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, P, P, P, c_size_t, P, c_int, P, P, P, P, c_int64, c_int,
+                                    c_int, c_int, P]),
     'mmi_cast_f32_bf16': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_cast_bf16_f32': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_add_bf16': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P]),

@@ -80,7 +80,6 @@ def conv_dgrad(dy, w, dx, d, s):
 def rows_of(t):
     """Return (tensor, ld): `tensor` is `t` (or a compacted copy) viewed as rows x C with unit channel stride and a
     uniform row stride ld."""
-    t = getattr(t, 'mmi_data', t)      # (bf16 storage: the carrier's real tensor, see wrap())
     assert t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda, 'mmidet_hip ops need fp32 (or bf16-storage) tensors on the MI355X'
     C = t.shape[-1]
     if t.is_contiguous():          # the common case
@@ -258,47 +257,10 @@ def join_pending():
 
 
 BF16 = torch.bfloat16
-# bf16 storage mode: gradients that travel BETWEEN autograd nodes stay fp32 (only a Conv's BatchNorm-backward output, which
-# feeds its two GEMMs and nothing else, is bf16).  A train-mode BatchNorm backward projects the per-channel common mode out of
-# its incoming gradient; rounding that gradient to 8 mantissa bits first leaves noise of the order of what remains: measured
-# 40-60 % per-tensor gradient error with bf16 gradients against 0.5 % with fp32 ones on the same bf16 activations
-# (profiles/r02_bf16_gradient_diag*.txt).  MMIDET_BF16_GRADS=1 switches back (A/B).
-GRAD_F32 = __import__("os").environ.get("MMIDET_BF16_GRADS", "0") != "1"
-
-
-def grad_dtype(storage_dtype):
-    return torch.float32 if (GRAD_F32 or storage_dtype == torch.float32) else storage_dtype
-
-
-# autograd insists that the gradient of an edge has the dtype of the tensor on that edge (it silently casts otherwise).  So in
-# bf16 storage mode the tensor autograd sees between two nodes is a CARRIER: an fp32-typed, zero-stride, zero-cost view of one
-# shared scalar with the activation's shape, whose attribute `mmi_data` is the real bf16 tensor.  The ops unwrap their
-# inputs (rows_of / data) and wrap their bf16 outputs; the gradients autograd routes along those edges are real fp32 tensors.
-_carrier_base = {}
-
-
-def wrap(t):
-    if t.dtype != BF16 or not GRAD_F32:
-        return t
-    base = _carrier_base.get(t.device)
-    if base is None:
-        base = _carrier_base[t.device] = torch.zeros(1, dtype=torch.float32, device=t.device)
-    c = base.expand(t.shape)
-    c.mmi_data = t
-    return c
-
-
-def data(t):
-    return getattr(t, 'mmi_data', t)
-
-
-def storage_dtype(t):
-    return data(t).dtype
 
 
 def raw_cast(t, dtype):
     """fp32 <-> bf16 copy of an NHWC / rows tensor (no autograd): the storage-mode boundary (csrc/bf16_ops.hip)."""
-    t = getattr(t, 'mmi_data', t)
     if t.dtype == dtype:
         return t
     t, ld = rows_of(t)
@@ -312,16 +274,16 @@ def raw_cast(t, dtype):
 class _Cast(Function):
     @staticmethod
     def forward(ctx, x, dtype):
-        ctx.src = storage_dtype(x)
-        return wrap(raw_cast(x, dtype))
+        ctx.src = x.dtype
+        return raw_cast(x, dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return raw_cast(g, grad_dtype(ctx.src)), None
+        return raw_cast(g, ctx.src), None
 
 
 def cast(x, dtype):
-    return x if storage_dtype(x) == dtype else _Cast.apply(x, dtype)
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
 
 class Dest:
@@ -404,21 +366,15 @@ def _bn_act_fwd(y, ldy, mi, gamma, beta, residual, ldr, out, ldo, out1, ldo1, sp
 def _bn_act_bwd(y, ldy, dout, ldd, dout1, ldd1, split, mi, gamma, beta, dy, dgs, rows, c, act, frozen, s):
     nbw = bn_bwd_ws(rows, c)
     ws = zeroed_scratch(nbw, y.device, s, tag='bn')
-    tail = (mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), nbw, dy.data_ptr(), c, dgs[0].data_ptr(), dgs[1].data_ptr(),
-            dgs[2].data_ptr() if dgs[2] is not None else None, dgs[3].data_ptr() if dgs[3] is not None else None, rows, c, act, frozen, s)
-    d1 = dout1.data_ptr() if dout1 is not None else None
-    if y.dtype == BF16:
-        assert dout1 is None or dout1.dtype == dout.dtype
-        lib.bn_act_bwd_bf16(y.data_ptr(), ldy, dout.data_ptr(), ldd, d1, ldd1, split, 1 if dout.dtype == torch.float32 else 0, *tail)
-    else:
-        lib.bn_act_bwd(y.data_ptr(), ldy, dout.data_ptr(), ldd, d1, ldd1, split, *tail)
+    fn = lib.bn_act_bwd_bf16 if y.dtype == BF16 else lib.bn_act_bwd
+    fn(y.data_ptr(), ldy, dout.data_ptr(), ldd, dout1.data_ptr() if dout1 is not None else None, ldd1, split, mi.data_ptr(),
+       gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), nbw, dy.data_ptr(), c, dgs[0].data_ptr(), dgs[1].data_ptr(),
+       dgs[2].data_ptr() if dgs[2] is not None else None, dgs[3].data_ptr() if dgs[3] is not None else None, rows, c, act, frozen, s)
 
 
 def _conv_dgrad_any(dy, w, dx, dd, s, skip=None, lds=0):
     if dy.dtype == BF16:
-        assert skip is None or skip.dtype == dx.dtype
-        lib.conv_dgrad_bf16(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), skip.data_ptr() if skip is not None else None, lds,
-                            1 if dx.dtype == torch.float32 else 0, dd, s)
+        lib.conv_dgrad_bf16(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), skip.data_ptr() if skip is not None else None, lds, dd, s)
     else:
         assert skip is None
         conv_dgrad(dy, w, dx, dd, s)
@@ -429,13 +385,12 @@ def _dgrad_accumulate(dy, w, dx, d, dd, skip, s):
     of their own."""
     skip, lds = rows_of(skip)
     if dy.dtype == BF16:
-        skip, lds = rows_of(raw_cast(skip, dx.dtype))
+        skip = raw_cast(skip, BF16)
         if d.KH == 1 and d.stride == 1 and lds % 4 == 0:
             _conv_dgrad_any(dy, w, dx, dd, s, skip, lds)
         else:
             _conv_dgrad_any(dy, w, dx, dd, s)
-            (lib.add_bf16 if dx.dtype == BF16 else lib.add)(dx.data_ptr(), d.Cin, skip.data_ptr(), lds, dx.data_ptr(), d.Cin, _nrows(dx),
-                                                            d.Cin, s)
+            lib.add_bf16(dx.data_ptr(), d.Cin, skip.data_ptr(), lds, dx.data_ptr(), d.Cin, _nrows(dx), d.Cin, s)
         return
     if d.KH == 1 and d.stride == 1 and d.Cin % 4 == 0 and d.Cout % 4 == 0 and dd.ldy % 4 == 0 and lds % 4 == 0:
         nb = lib.conv_dgrad_workspace(dd)
@@ -457,8 +412,6 @@ class _ConvBnAct(Function):
     def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, residual, stride, act, training, eps, momentum, skip, dest):
         x_in = x
         x, ldx = rows_of(x)
-        if data(x_in) is not x_in:
-            x_in = wrap(data(x_in))       # (a fresh carrier: an input returned as an output would lose its attribute)
         w = _ohwi(w)
         cout, k = w.shape[0], w.shape[2]
         d = _desc(x.shape, cout, k, stride, ldx, cout)
@@ -475,14 +428,13 @@ class _ConvBnAct(Function):
         _bn_act_fwd(y, cout, mi, gamma, beta, residual, ldr, out, ldo, None, 0, cout, rows, cout, act, s)
         ctx.save_for_backward(x, w, y, mi, gamma, beta)
         ctx.cfg = (d, act, training, residual is not None, skip)
-        out = wrap(out)
         return (out, x_in) if skip else out
 
     @staticmethod
     def backward(ctx, dout, dskip=None):
         x, w, y, mi, gamma, beta = ctx.saved_tensors
         d, act, training, has_res, skip = ctx.cfg
-        dout, ldd = rows_of(dout if y.dtype == BF16 else raw_cast(dout, y.dtype))
+        dout, ldd = rows_of(raw_cast(dout, y.dtype))
         cout = d.Cout
         rows = d.N * d.Ho * d.Wo
         s = _stream()
@@ -495,7 +447,7 @@ class _ConvBnAct(Function):
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=grad_dtype(x.dtype), device=x.device)
+            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
             if skip and dskip is not None:
                 _dgrad_accumulate(dy, w, dx, d, dd, dskip, s)
@@ -544,20 +496,15 @@ class _DualConvBnAct(Function):
         _bn_act_fwd(y, cout, mi, g1, b1, None, 0, a, c_, b, ldb, c_, rows, cout, act, s)
         ctx.save_for_backward(x, w1, w2, y, mi, g1, b1, g2, b2)
         ctx.cfg = (d, act, training, c_)
-        return wrap(a), wrap(b)
+        return a, b
 
     @staticmethod
     def backward(ctx, da, db):
         x, w1, w2, y, mi, g1, b1, g2, b2 = ctx.saved_tensors
         d, act, training, c_ = ctx.cfg
         cout, rows, s = 2 * c_, d.N * d.Ho * d.Wo, _stream()
-        if y.dtype == BF16:
-            gd = da.dtype if da.dtype == db.dtype else torch.float32
-            da, db = raw_cast(da, gd), raw_cast(db, gd)
-        else:
-            da, db = raw_cast(da, y.dtype), raw_cast(db, y.dtype)
-        da, lda = rows_of(da)
-        db, ldb = rows_of(db)
+        da, lda = rows_of(raw_cast(da, y.dtype))
+        db, ldb = rows_of(raw_cast(db, y.dtype))
         dy = torch.empty_like(y)
         dg1, dbt1, dg2, dbt2 = grad_like(g1), grad_like(b1), grad_like(g2), grad_like(b2)
         _bn_act_bwd(y, cout, da, lda, db, ldb, c_, mi, g1, b1, dy, (dg1, dbt1, dg2, dbt2), rows, cout, act, 0 if training else 1, s)
@@ -567,7 +514,7 @@ class _DualConvBnAct(Function):
         dw2 = _wgrad(dy[..., c_:], cout, x, d.ldx, w2, d1, overlap=both) if ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=grad_dtype(x.dtype), device=x.device)
+            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.Cin, cout)
             _conv_dgrad_any(dy, w1, dx, dd, s)
         if both:
@@ -586,12 +533,11 @@ class _CatAlias(Function):
     @staticmethod
     def forward(ctx, a, b, holder):
         cat = holder.t
-        a, b = data(a), data(b)
         ca = a.shape[-1]
         assert a.data_ptr() == cat.data_ptr() and b.data_ptr() == cat.data_ptr() + cat.element_size() * ca and ca + b.shape[-1] == cat.shape[-1], \
             'cat_alias: the inputs are not the channel halves of the buffer'
         ctx.ca = ca
-        return wrap(cat)
+        return cat
 
     @staticmethod
     def backward(ctx, g):
@@ -638,7 +584,6 @@ class _ConvBias(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride):
-        x = data(x)
         ctx.src = x.dtype
         if x.dtype == BF16 and (w.shape[0] % 4 != 0 or x.shape[-1] % 4 != 0):
             x = raw_cast(x, torch.float32)       # (a Detect head has 3*(nc+5) = 33 columns: the bf16 kernels want multiples of 4)
@@ -685,7 +630,7 @@ class _ConvBias(Function):
             else:
                 dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(tuple(x.shape), dtype=grad_dtype(x.dtype), device=x.device)
+            dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
             _conv_dgrad_any(dy, w, dx, dd, s)
         if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
@@ -694,8 +639,8 @@ class _ConvBias(Function):
             lib.colsum(dy.data_ptr(), lddy, rows, d.Cout, part.data_ptr(), db.data_ptr(), s)
         if both:
             _join_side(x.device)
-        if dx is not None and dx.dtype != grad_dtype(ctx.src):
-            dx = raw_cast(dx, grad_dtype(ctx.src))
+        if dx is not None and dx.dtype != ctx.src:
+            dx = raw_cast(dx, ctx.src)
         return dx, dw, db, None
 
 
@@ -773,7 +718,7 @@ class _Add(Function):
         c = a.shape[-1]
         assert a.dtype == b.dtype
         (lib.add_bf16 if a.dtype == BF16 else lib.add)(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), c, _nrows(a), c, _stream())
-        return wrap(out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -789,7 +734,6 @@ class _Concat(Function):
 
     @staticmethod
     def forward(ctx, *xs):
-        xs = [data(x) for x in xs]
         ctot = sum(x.shape[-1] for x in xs)
         out = torch.empty((*xs[0].shape[:-1], ctot), dtype=xs[0].dtype, device=xs[0].device)
         off = 0
@@ -802,7 +746,7 @@ class _Concat(Function):
             cp(x.data_ptr(), ld, out.data_ptr() + es * off, ctot, _nrows(x), c, s)
             off += c
         ctx.sizes = [x.shape[-1] for x in xs]
-        return wrap(out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -827,7 +771,7 @@ class _Upsample2x(Function):
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
         (lib.upsample2x_bf16 if x.dtype == BF16 else lib.upsample2x)(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
-        return wrap(y)
+        return y
 
     @staticmethod
     def backward(ctx, g):
@@ -847,13 +791,13 @@ class _SppPool(Function):
 
     @staticmethod
     def forward(ctx, x):
-        ctx.src = storage_dtype(x)
+        ctx.src = x.dtype
         x, ld = rows_of(raw_cast(x, torch.float32))      # (bf16 storage: a P5-sized map; the pooling kernels are fp32)
         n, h, w, c = x.shape
         out = torch.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
         lib.spp_pool_fwd(x.data_ptr(), ld, out.data_ptr(), 4 * c, n, h, w, c, _stream())
         ctx.save_for_backward(x)
-        return wrap(raw_cast(out, ctx.src))
+        return raw_cast(out, ctx.src)
 
     @staticmethod
     def backward(ctx, g):
@@ -863,7 +807,7 @@ class _SppPool(Function):
         n, h, w, c = x.shape
         dx = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.spp_pool_bwd(x.data_ptr(), ld, g.data_ptr(), ldg, dx.data_ptr(), c, n, h, w, c, _stream())
-        return raw_cast(dx, grad_dtype(ctx.src))
+        return raw_cast(dx, ctx.src)
 
 
 def spp_pool(x):

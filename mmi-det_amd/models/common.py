@@ -118,7 +118,7 @@ class C3(nn.Module):
         # cv1 | cv2 as one GEMM; the concat buffer is written in place by its two producers (models/common.py:650 without the copy)
         a, b = self.cv1, self.cv2
         c_ = a.conv.weight.shape[0]
-        cat = ops.Dest(torch.empty((*x.shape[:-1], 2 * c_), dtype=ops.storage_dtype(x), device=x.device))
+        cat = ops.Dest(torch.empty((*x.shape[:-1], 2 * c_), dtype=x.dtype, device=x.device))
         h, b_out = ops.dual_conv_bn_act(x, a.conv.weight, b.conv.weight, a.bn.weight, a.bn.bias, b.bn.weight, b.bn.bias,
                                         a.bn.running_mean, a.bn.running_var, a.bn.num_batches_tracked,
                                         b.bn.num_batches_tracked, a._act_id(), a.bn.training, a.bn.eps, a.bn.momentum,

@@ -29,7 +29,7 @@ logger = logging.getLogger(__name__)
 
 def _tensors_of(obj):
     if torch.is_tensor(obj):
-        return [ops.data(obj)]          # (bf16 storage: the real tensor behind the carrier)
+        return [obj]
     if isinstance(obj, FusedTokens):
         return list(obj.maps)
     if isinstance(obj, (list, tuple)):

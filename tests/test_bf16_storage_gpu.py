@@ -64,9 +64,9 @@ def test_conv_bn_act_bf16_storage(case, residual):
     nbt = torch.zeros((), dtype=torch.long, device=d)
     outg = ops.conv_bn_act(xg, wg, gg, bg, rmg, rvg, nbt, stride=s, act=act, residual=xg if residual else None)
     assert outg.dtype == BF
-    outg.backward(nhwc(gy).to(d))
+    outg.backward(nhwc(gy).to(d).to(BF))
     torch.cuda.synchronize()
-    assert wg.grad.dtype == torch.float32      # (the input gradient is fp32: gradients between layers are, see ops.GRAD_F32)
+    assert xg.grad.dtype == BF and wg.grad.dtype == torch.float32
     close(nchw(outg.float()), outr, tol=1e-2, what='out')
     assert int(nbt) == 1
     # (one image of 17x19 pixels through a training-mode BatchNorm + LeakyReLU: the BN backward subtracts two nearly equal
@@ -96,7 +96,7 @@ def test_c3_bf16_storage_matches_fp32(cfg):
     ya, yb = a(xa), b(xb)
     assert yb.dtype == BF
     ya.backward(gy.float())
-    yb.backward(gy.float())
+    yb.backward(gy)
     torch.cuda.synchronize()
     close(yb.float(), ya, tol=2e-2, what='out')
     close(xb.grad.float(), xa.grad, tol=4e-2, what='dx')
