@@ -105,9 +105,16 @@ def test_c3_bf16_storage_matches_fp32(cfg):
 
 
 @pytest.mark.parametrize('kind', ['add', 'fourier'])
-def test_graph_bf16_storage_tracks_fp32(kind):
+@pytest.mark.parametrize('bn', ['frozen', 'train'])
+def test_graph_bf16_storage_tracks_fp32(kind, bn):
     """Whole tiny graphs: forward + loss + backward with model.storage = 'bf16' against the fp32 mode on the same weights and
-    batch: predictions and loss at bf16 accuracy, every gradient finite, medians of the per-tensor gradient errors small."""
+    batch.  With the BatchNorm layers FROZEN (running statistics) every parameter gradient agrees to bf16 accuracy (median
+    5e-3, cosine 0.999+): the kernels, casts and glue of the mode are right.  With training-mode BatchNorm on these
+    hash-initialised graphs the same 2^-9 roundings are amplified ~100-fold on the way through the depth -- in the FORWARD
+    already (the feature part of the predictions moves by tens of per cent; fp32's 6e-8 becomes the 6e-6..2e-5 the fp32 tests
+    see) -- so gradients differ by 40-60 % per tensor while pointing the same way (cosine 0.7-0.9;
+    profiles/r02_bf16_gradient_diag.txt).  That is a property of the untrained network's conditioning, not of a kernel: there
+    the test bounds the loss, the predictions and the gradient DIRECTION only."""
     from test_model_gpu import build_pair
     from oracle import portable_init
     from utils.loss import ComputeLoss
@@ -119,6 +126,10 @@ def test_graph_bf16_storage_tracks_fp32(kind):
     res = []
     for m in (m32, mbf):
         m.train()
+        if bn == 'frozen':
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.eval()
         p, c = m(x[:, :3], x[:, 3:])
         loss, items = ComputeLoss(m)(p, targets.to(dev()), c.reshape(-1))
         loss.backward()
@@ -127,17 +138,22 @@ def test_graph_bf16_storage_tracks_fp32(kind):
     (p32, l32, i32), (pbf, lbf, ibf) = res
     for i in range(3):
         assert pbf[i].dtype == torch.float32
-        # (hash-initialised tiny graphs at 128x128, batch 2: 16..256-pixel maps under training-mode BatchNorm; measured 2e-2..4.3e-2)
-        close(pbf[i], p32[i], tol=8e-2, what='pred%d' % i)
-    close(lbf, l32, tol=2e-2, what='loss')
-    errs = []
+        close(pbf[i], p32[i], tol=2e-2 if bn == 'frozen' else 8e-2, what='pred%d' % i)
+    close(lbf, l32, tol=1e-2 if bn == 'frozen' else 3e-2, what='loss')
+    errs, coss = [], []
     for (n, p), q in zip(m32.named_parameters(), mbf.parameters()):
         if p.grad is None or float(p.grad.norm()) < 1e-9:
             continue
         assert torch.isfinite(q.grad).all(), n
         errs.append(rel_err(q.grad, p.grad))
+        coss.append(float((q.grad.double() * p.grad.double()).sum() / (q.grad.double().norm() * p.grad.double().norm() + 1e-30)))
     errs.sort()
-    assert errs[len(errs) // 2] < 5e-2, (errs[len(errs) // 2], errs[-3:])
+    coss.sort()
+    if bn == 'frozen':
+        assert errs[len(errs) // 2] < 3e-2 and errs[int(0.9 * len(errs))] < 0.15, (errs[len(errs) // 2], errs[-3:])
+        assert coss[len(coss) // 10] > 0.99, coss[:3]
+    else:
+        assert coss[len(coss) // 2] > 0.6, (coss[len(coss) // 2], coss[:3])
 
 
 def test_bf16_storage_training_overfits_one_batch():
