@@ -395,7 +395,9 @@ def main():
             print('[bench %.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     from mmidet_hip import lib as _lib
-    _lib.set_gemm_precision({'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16x9': 3}[args.gemm])
+    # bf16 storage: the GEMMs whose operands stay fp32 in HBM (token-side Linear layers, Focus, Detect heads) take the same
+    # single-product bf16 arithmetic (mode 5 = "bf16x1")
+    _lib.set_gemm_precision(5 if args.storage == 'bf16' else {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16x9': 3}[args.gemm])
     note('model on device, %d params; warmup' % sum(p.numel() for p in model.parameters()))
     for i in range(args.warmup):
         ts.step(imgs, tg)

@@ -277,7 +277,7 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 #define MMI_UNI_OCC 3
 #endif
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC == 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
   // PREC = 4 (bf16 STORAGE): the activation operand A and the output C live in HBM as bf16 (the weights stay
@@ -285,11 +285,14 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   // BatchNorm statistics taken from the accumulators.  Same tile machinery as the split forms with a single plane.
   constexpr bool BF = PREC == 4;
   static_assert(!BF || !UNI, "bf16 storage uses the cursor loaders");
-  constexpr int NP = PREC == 0 || BF ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
-  constexpr int OL = BF ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);          // highest total order of the products kept
+  // PREC = 5 ("bf16x1"): fp32 operands in HBM, each rounded to ONE bf16 term when staged, one bf16 MFMA product: the arithmetic of
+  // the bf16-storage mode for the GEMMs whose operands stay fp32 (the token-side Linear layers, Focus, Detect)
+  constexpr bool ONE = BF || PREC == 5;
+  constexpr int NP = PREC == 0 || ONE ? 1 : (PREC == 3 ? 3 : PREC + 1);      // bf16 planes per operand
+  constexpr int OL = ONE ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);          // highest total order of the products kept
   // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (20, 36 or 52 floats: each makes
   // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
-  constexpr int RSF = BF ? 20 : (PREC >= 2 ? 52 : LDS_PAD);
+  constexpr int RSF = ONE ? 20 : (PREC >= 2 ? 52 : LDS_PAD);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * RSF;
@@ -878,13 +881,14 @@ struct WgradP {
 // a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
 // resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
 template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
-__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC == 4)) ? 3 : 2)) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP p) {
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
   static_assert(!BF || !TAB, "bf16 storage uses the cursor loaders");
-  constexpr int NP = PREC == 0 || BF ? 1 : (PREC == 3 ? 3 : PREC + 1);
-  constexpr int OL = BF ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
+  constexpr bool ONE = BF || PREC == 5;   // PREC = 5: fp32 operands, one bf16 term each (see igemm_kernel)
+  constexpr int NP = PREC == 0 || ONE ? 1 : (PREC == 3 ? 3 : PREC + 1);
+  constexpr int OL = ONE ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
@@ -1456,7 +1460,7 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
   if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(Ncol, 64);
   static const bool off = getenv("MMIDET_NO_STREAMK") != nullptr;
   const int nk = cdiv(Ktot, BK);
-  if (!vec || !allow_sk || g_tile_bm > 0) return f;
+  if (!vec || !allow_sk || g_tile_bm > 0 || g_gemm_prec == 5) return f;   // (mode 5: short launches, one workgroup per tile)
   FwdPlan g;
   g.bm = 128;
   g.bn = Ncol > 64 ? 128 : 64;
@@ -1580,6 +1584,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   do {                                                                                                               \
     if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1, EPI>), grid, block, 0, s, p); \
     else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI>), grid, block, 0, s, p); \
+    else if (g_gemm_prec == 5) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 5, EPI>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI>), grid, block, 0, s, p);                  \
   } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
@@ -1640,7 +1645,8 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d) {
 }  // namespace
 
 extern "C" int mmi_set_gemm_precision(int mode) {
-  MMI_CHECK_ARG(mode >= 0 && mode <= 3, "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9)", mode);
+  MMI_CHECK_ARG((mode >= 0 && mode <= 3) || mode == 5,
+                "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9, 5 = bf16x1)", mode);
   g_gemm_prec = mode;
   return MMI_OK;
 }
@@ -1869,7 +1875,7 @@ int wgrad_slots(int bm, int bn, bool vec) {
     (void)hipGetLastError();
   }
   // (the three-term split variants hold 1.5x the LDS and more registers: two workgroups per CU for the wide tiles)
-  const int per_cu = (g_gemm_prec >= 2 && idx >= 1 && idx <= 3 && cache[idx] > 2) ? 2 : cache[idx];
+  const int per_cu = ((g_gemm_prec == 2 || g_gemm_prec == 3) && idx >= 1 && idx <= 3 && cache[idx] > 2) ? 2 : cache[idx];
   return per_cu * device_cus();
 }
 
@@ -2040,6 +2046,7 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   do {                                                                                                  \
     if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p);  \
     else if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p); \
+    else if (g_gemm_prec == 5) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 5>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3>), grid, block, 0, s, p);                   \
   } while (0)
     if (g.bm == 128 && g.bn == 128) LAUNCHW3(128, 128);
