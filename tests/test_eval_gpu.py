@@ -127,6 +127,28 @@ def test_nms_edge_cases():
         assert bool((a[1:, 4] <= a[:-1, 4]).all())                    # sorted by confidence
 
 
+def test_nms_a_priori_labels_and_candidate_cap():
+    """general.py:519-526 (labels) and :501,557-559 (max_nms = 30 000): test.py's settings on a full 640x640 row count with
+    every row live -- 25 200 rows x 6 classes = ~150 000 candidate pairs, of which the 30 000 most confident take part."""
+    from oracle import ref_nms
+    from utils.general import non_max_suppression
+    d = dev()
+    pred = ref_nms.synth_predictions(31, bs=2, rows=300, nc=4)
+    labels = [torch.tensor([[1, 320., 320., 100., 80.], [3, 100., 500., 60., 60.]]), torch.zeros((0, 5))]
+    out = non_max_suppression(pred.to(d), labels=labels)
+    ref = ref_nms.non_max_suppression(pred, labels=labels)
+    for a, b in zip(out, ref):
+        assert torch.equal(a.cpu(), b)
+    assert float(out[0][0, 4]) == 1.0                                  # the a-priori boxes lead with confidence 1
+    pred = ref_nms.synth_predictions(32, bs=2, rows=25200, nc=6)
+    pred[1, :, 4] *= (torch.arange(25200) % 40 == 0).float()          # image 1 stays far below the cap
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    out = non_max_suppression(pred.to(d), **kw)
+    ref = ref_nms.non_max_suppression(pred, **kw)
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b)
+
+
 def test_checkpoint_to_detections(tmp_path):
     """detect_twostream.py:33,89-93 end to end: whole-object checkpoint -> attempt_load (fp32, fused, eval) -> forward ->
     non_max_suppression; the detections equal those of the model that was saved (unfused) up to fp32 rounding."""
