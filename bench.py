@@ -345,7 +345,13 @@ def main():
             # through the library's own communicator on the reducer's HIP stream: no ProcessGroupNCCL, no watchdog thread
             from mmidet_hip.ddp import init_native_comm
             dist.init_process_group('gloo', rank=rank, world_size=world)
-            init_native_comm(rank, world)
+            try:
+                init_native_comm(rank, world)
+            except Exception as e:      # (RCCL could not be bound or initialised: the same on every rank -> fall back together)
+                print('[bench] native RCCL transport unavailable (%r); falling back to torch.distributed/nccl' % (e,), file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                comm_kind = 'torch'
+                dist.init_process_group('nccl', rank=rank, world_size=world)
         else:
             # (no device_id=: binding the group to the device at init makes every later step ~5 ms slower on this
             # torch/RCCL; torch.cuda.set_device above already pins the rank to its GPU)
@@ -378,6 +384,8 @@ def main():
         from mmidet_hip.ddp import GradReducer
         red = GradReducer(list(model.parameters()))
         red.broadcast_parameters(model)
+        if ts.ema is not None:
+            red.broadcast_parameters(ts.ema.ema)      # (the EMA copy was taken from the rank-local initialisation)
         ts.reducer = red
     imgs, tg = synth(bs, size, nc, dev, 100 + rank)
 

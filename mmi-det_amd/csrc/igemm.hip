@@ -1908,11 +1908,14 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   int cap = tiles > 64 ? 16 : cdiv(2 * slots, tiles);
   if (cap > max_splits) cap = max_splits;
   if (cap < 1) cap = 1;
+  // Every split costs a slab of dw to write and to read back: a split count is charged `pen` of wave efficiency per split
+  // (MMIDET_WGRAD_SPLIT_PENALTY, default 0: the round-1 rule -- fill whole waves, fewer splits win ties)
+  static const double pen = getenv("MMIDET_WGRAD_SPLIT_PENALTY") ? atof(getenv("MMIDET_WGRAD_SPLIT_PENALTY")) : 0.0;
   int splits = 1;
-  double best = 0.0;
+  double best = -1e9;
   for (int sp = 1; sp <= cap; ++sp) {
     const int blocks = tiles * sp;
-    const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots);
+    const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots) - pen * sp;
     if (eff > best + 1e-9) best = eff, splits = sp;
   }
   g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;

@@ -13,5 +13,9 @@ run MMIDET_PACK_C3=0
 run MMIDET_SKIP_FUSE=0
 run MMIDET_WGRAD_FOLD=0
 run MMIDET_WGRAD_TABLE=0
+run MMIDET_WGRAD_SPLIT_PENALTY=0.005
+run MMIDET_WGRAD_SPLIT_PENALTY=0.01
+run MMIDET_WGRAD_SPLIT_PENALTY=0.02
+run MMIDET_WGRAD_SPLIT_PENALTY=0.01 MMIDET_WGRAD_FOLD_MAX=8
 run MMIDET_BN_FOLD=0 MMIDET_PACK_C3=0 MMIDET_SKIP_FUSE=0 MMIDET_WGRAD_FOLD=0
 run X=1
