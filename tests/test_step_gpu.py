@@ -105,8 +105,6 @@ def test_whole_step_graph_matches_eager():
     # the capture pass itself runs two warm-up steps on the first batch: mirror them on the eager side
     for _ in range(2):
         ts2.step(*batches[0])
-    # (two trainings are not bit-identical run to run -- fp32 atomics in a few reductions -- and a flipped max-pool tie
-    # moves a later loss by ~0.25 %, see tools/det_check.py: tight on the first steps, loose afterwards)
     # (round 2: no float atomics are left on the path, every kernel is run-to-run deterministic, and the captured step runs the
     #  same kernels as the eager one -- only on fewer streams -- so the round-1 tolerances of 1e-3 .. 6e-3 are now 1e-5)
     for (imgs, tg), tol in zip(batches, (1e-5, 1e-5, 1e-5, 1e-5)):
@@ -172,15 +170,12 @@ def test_data_parallel_graph_step_matches_whole_step_graph():
         m2, ts2, _ = make(graph=True)
         ts2.reducer = GradReducer(list(m2.parameters()))
         batches = [batch(cfg, 30 + i) for i in range(3)]
-        # Two trainings of the same net are not bit-identical run to run (fp32 atomics in a few reductions); by the third
-        # step a flipped max-pool tie moves the loss by ~0.25 % (tools/det_check.py shows the same spread between two
-        # identical single-GPU runs), hence the per-step tolerances.
         for (imgs, tg), tol in zip(batches, (1e-5, 1e-5, 1e-5)):
             l1, i1 = ts1.step(imgs, tg)
             l2, i2 = ts2.step(imgs, tg)
             close(l1, l2, what='loss', tol=tol)
             close(i1, i2, what='items', tol=tol)
-        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=6e-3)
+        close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights', tol=1e-5)
         close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=1e-5)
     finally:
         from mmidet_hip import ops
@@ -215,9 +210,7 @@ def test_data_parallel_eager_writes_gradients_into_the_buckets():
         ts2._update()
         assert all(p.grad is None for p in m2.parameters())
         ts1.step(imgs, tg)
-        # (two runs of the same step differ in the last bits -- fp32 atomics in the statistics kernels, bucket-view vs fresh
-        # gradient memory -- and a flipped max-pool tie moves a later loss by up to 0.3 %: tools/det_check.py; the second step
-        # already sees weights that went through one such update, hence 1e-4 then 6e-3)
+        # (round 1 needed 1e-4 then 6e-3 here: fp32 atomics made two runs of one step differ in the last bits; they are gone)
         for it, tol in ((41, 1e-5), (42, 1e-5)):
             imgs, tg = batch(cfg, it)
             l1, _ = ts1.step(imgs, tg)
