@@ -20,9 +20,14 @@ dw = torch.empty_like(w)
 nb = lib.conv_wgrad_workspace(desc)
 ws = torch.zeros(max(nb // 4, 1), device=d)     # (arrival counters at its head: zero-filled once)
 part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Co, device=d)
+tb = lib.conv_wgrad_table_bytes(desc)        # round 2: the layer's precomputed pixel table (None: in-kernel builder)
+tab = None
+if tb and os.environ.get('MMIDET_WGRAD_TABLE', '1') != '0':
+    tab = torch.empty(tb, dtype=torch.uint8, device=d)
+    lib.conv_wgrad_table_build(tab.data_ptr(), desc, st)
 for _ in range(3):
     ops.conv_fwd(x, w, None, y, part, desc, st)
     ops.conv_dgrad(dy, w, dx, desc, st)
-    lib.conv_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
+    lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, tab.data_ptr() if tab is not None else None, desc, st)
 torch.cuda.synchronize()
 print('flop per launch', 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k)
