@@ -356,6 +356,19 @@ int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float
             int multi_label, int max_det, float max_wh, void* workspace, size_t workspace_bytes, float* out, int* nout,
             void* stream);
 
+/* ---- fused Contour Enhancement forward (models/common.py:751-803 AdaptiveModule3 + 806-911
+ * EnhanceConv2d with the reference's frozen stencil bank): x (N,H,W,3) -> y3 = conv3(t), t = r + factor * stencil(sum_c r_c) +
+ * bias, r = LeakyReLU(BN2(conv2(x))), one 16x16 tile per workgroup with r and t in LDS (x staged with a halo of 3).  BN2's
+ * batch statistics come from a recompute pre-pass (mmi_cem_conv2_stats -> partials[mmi_cem_blocks][2][24] -> mmi_bn_finalize);
+ * y3's statistics partials [mmi_cem_blocks][2][3] come out of the fused kernel, the output of the module is then
+ * mmi_bn_act_fwd(y3, ..., residual = x).  y2, t (24 channels) and the channel-sum map are written for the backward when
+ * non-NULL (training); inference passes NULL and moves 1 read of x + 1 write of y3.  w2 = [24][9][3], w3 = [3][9][24] (OHWI). */
+int mmi_cem_blocks(int N, int H, int W);
+int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_partials, int N, int H, int W, void* stream);
+int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const float* mean_invstd2, const float* gamma2, const float* beta2,
+                      const float* factor, const float* sobel_bias, const float* w3, float* y2, float* t, float* chansum, float* y3,
+                      float* stat_partials3, int N, int H, int W, void* stream);
+
 /* ---- bf16 storage (the reference trains under torch.cuda.amp, train.py:706,784,796-801) ---------
  * Opt-in second numeric mode of the conv family and its glue: activations and activation gradients are bf16 in HBM (NHWC,
  * same row-stride convention, counted in ELEMENTS), weights / weight gradients / BatchNorm parameters and statistics stay

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void smallconv_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] += bias[o];
   }
-  if (live) {
+  if (live && y != nullptr) {  // (y == nullptr: statistics pre-pass of the fused CEM forward, nothing is stored)
     float* dst = y + (((int64_t)n * H + oh) * W + ow) * ldy;
 #pragma unroll
     for (int o = 0; o < COUT; ++o) dst[o] = acc[o];
@@ -252,6 +252,160 @@ __global__ void sobel_add_fwd_kernel(const float* __restrict__ r, int ldr, const
   }
 }
 
+// ---- fused CEM forward: x -> conv2 -> BN2 + LeakyReLU -> r + stencil bank -> conv3, one 16x16 output
+// tile per workgroup with everything between x and y3 in LDS: x is staged with a halo of 3, r (24 channels) and its channel
+// sum are computed on the 20x20 region the stencils of the 18x18 t-region need, t on the 18x18 region conv3 needs.  BN2's
+// batch statistics come from a recompute pre-pass (smallconv_kernel<3,24> with y = nullptr).  What the backward needs is
+// written on the way -- y2, t (24 channels each), the channel-sum map and y3 with its statistics partials -- so HBM sees
+// 1 read of x and 1 write each of y2 / t instead of the 4 reads + 4 writes of 24-channel maps of the unfused chain.
+// Positions outside the image contribute zeros exactly where the reference's zero padding puts them (r for the stencils,
+// t for conv3).
+
+// (the read-only operands are separate __restrict__ kernel arguments, not struct members: only then does hipcc fetch the 1300
+//  uniform weights with scalar loads; through a by-value struct they became vector loads held in 256 VGPRs)
+struct CemOut {
+  float* y2;
+  float* t;
+  float* chansum;
+  float* y3;
+  float* stat_part;
+};
+__global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restrict__ px, const float* __restrict__ pw2,
+                                                            const float* __restrict__ pmi2, const float* __restrict__ pg2,
+                                                            const float* __restrict__ pb2, const float* __restrict__ pfactor,
+                                                            const float* __restrict__ psbias, const float* __restrict__ pw3,
+                                                            CemOut out, int ldx, int H_, int W_) {
+  struct {
+    const float* __restrict__ x; const float* __restrict__ w2; const float* __restrict__ mi2; const float* __restrict__ g2;
+    const float* __restrict__ b2; const float* __restrict__ factor; const float* __restrict__ sbias; const float* __restrict__ w3;
+    float* y2; float* t; float* chansum; float* y3; float* stat_part; int ldx, H, W;
+  } p{px, pw2, pmi2, pg2, pb2, pfactor, psbias, pw3, out.y2, out.t, out.chansum, out.y3, out.stat_part, ldx, H_, W_};
+  constexpr int XS = TS + 6, RS = TS + 4, TT = TS + 2;       // 22, 20, 18
+  __shared__ float xs[XS * XS * 3];
+  __shared__ __align__(16) float rs[RS * RS * 24];
+  __shared__ float cs[RS * RS];
+  __shared__ __align__(16) float ts[TT * TT * 24];
+  __shared__ float red[2][4][3];
+  const int t = threadIdx.x, n = blockIdx.z;
+  const int h0 = blockIdx.y * TS, w0 = blockIdx.x * TS;
+  const int H = p.H, W = p.W;
+  for (int e = t; e < XS * XS * 3; e += 256) {
+    const int c = e % 3, q = e / 3, ih = h0 - 3 + q / XS, iw = w0 - 3 + q % XS;
+    xs[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
+  }
+  __syncthreads();
+  // ---- r = LeakyReLU(BN2(conv2(x))) on the 20x20 region; zero outside the image
+#pragma unroll 1
+  for (int q = t; q < RS * RS; q += 256) {
+    asm volatile("" ::: "memory");   // keeps the 648 uniform weight loads inside the iteration (hoisted they cost 256 VGPRs)
+    const int i = q / RS, j = q % RS, ih = h0 - 2 + i, iw = w0 - 2 + j;
+    const bool in = ih >= 0 && iw >= 0 && ih < H && iw < W;
+    float acc[24];
+#pragma unroll
+    for (int o = 0; o < 24; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* src = xs + ((i + tap / 3) * XS + j + tap % 3) * 3;
+      const float x0 = src[0], x1 = src[1], x2 = src[2];
+#pragma unroll
+      for (int o = 0; o < 24; ++o) {
+        acc[o] += x0 * p.w2[(o * 9 + tap) * 3 + 0];
+        acc[o] += x1 * p.w2[(o * 9 + tap) * 3 + 1];
+        acc[o] += x2 * p.w2[(o * 9 + tap) * 3 + 2];
+      }
+    }
+    const bool interior = in && i >= 2 && i < RS - 2 && j >= 2 && j < RS - 2;
+    if (interior && p.y2 != nullptr) {
+      float* dst = p.y2 + (((int64_t)n * H + ih) * W + iw) * 24;
+#pragma unroll
+      for (int o = 0; o < 24; o += 4) *reinterpret_cast<f32x4*>(dst + o) = f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < 24; o += 4) {
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float z = (acc[o + k] - p.mi2[o + k]) * p.mi2[24 + o + k] * p.g2[o + k] + p.b2[o + k];
+        v[k] = in ? (z > 0.f ? z : 0.1f * z) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(rs + q * 24 + o) = v;
+      sum += (v[0] + v[1]) + (v[2] + v[3]);      // (the grouping of chansum_kernel)
+    }
+    cs[q] = sum;
+    if (interior && p.chansum != nullptr) p.chansum[((int64_t)n * H + ih) * W + iw] = sum;
+  }
+  __syncthreads();
+  // ---- t = r + factor * stencil(chansum) + bias on the 18x18 region; zero outside the image
+#pragma unroll 1
+  for (int q = t; q < TT * TT; q += 256) {
+    asm volatile("" ::: "memory");
+    const int i = q / TT, j = q % TT, ih = h0 - 1 + i, iw = w0 - 1 + j;
+    const bool in = ih >= 0 && iw >= 0 && ih < H && iw < W;
+    float nb[9], st[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) nb[k] = cs[(i + k / 3) * RS + j + k % 3];
+    stencils8(nb, st);
+    const float* rsrc = rs + ((i + 1) * RS + j + 1) * 24;
+    const bool interior = in && i >= 1 && i < TT - 1 && j >= 1 && j < TT - 1;
+    float* dst = (interior && p.t != nullptr) ? p.t + (((int64_t)n * H + ih) * W + iw) * 24 : nullptr;
+#pragma unroll
+    for (int o = 0; o < 24; o += 4) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(rsrc + o);
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = in ? rv[k] + p.factor[o + k] * st[(o + k) & 7] + p.sbias[o + k] : 0.f;
+      *reinterpret_cast<f32x4*>(ts + q * 24 + o) = v;
+      if (dst != nullptr) *reinterpret_cast<f32x4*>(dst + o) = v;
+    }
+  }
+  __syncthreads();
+  // ---- y3 = conv3(t) on the 16x16 tile (tap-major, channel-minor: the order of smallconv_kernel<24,3>)
+  const int ti = t >> 4, tj = t & 15, oh = h0 + ti, ow = w0 + tj;
+  const bool live = oh < H && ow < W;
+  float a3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1          // (fully unrolled, the 54 ds_read_b128 of the nine taps are all issued up front: 216 VGPRs)
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* src = ts + ((ti + tap / 3) * TT + tj + tap % 3) * 24;
+#pragma unroll
+    for (int c = 0; c < 24; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) a3[o] += v[k] * p.w3[(o * 9 + tap) * 24 + c + k];
+    }
+  }
+  if (live) {
+    float* dst = p.y3 + (((int64_t)n * H + oh) * W + ow) * 3;
+    dst[0] = a3[0];
+    dst[1] = a3[1];
+    dst[2] = a3[2];
+  }
+  if (p.stat_part != nullptr) {
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float s1 = live ? a3[o] : 0.f, s2 = s1 * s1;
+#pragma unroll
+      for (int k = 32; k > 0; k >>= 1) {
+        s1 += __shfl_xor(s1, k);
+        s2 += __shfl_xor(s2, k);
+      }
+      if (lane == 0) {
+        red[0][wv][o] = s1;
+        red[1][wv][o] = s2;
+      }
+    }
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (t < 6) {
+      const int sidx = t / 3, o = t - sidx * 3;
+      p.stat_part[((int64_t)blk * 2 + sidx) * 3 + o] = red[sidx][0][o] + red[sidx][1][o] + red[sidx][2][o] + red[sidx][3][o];
+    }
+  }
+}
+
 // backward pass 1: D[pix][k] = sum_{o%8==k} factor[o]*dt[pix][o]; partial sums of dbias[o] = sum dt_o and
 // dfactor[o] = sum dt_o * stencil_{o%8}(R): partials[block][2][C].  A thread walks SOBEL_PPT pixels (256 apart, so a wave
 // still reads consecutive pixels) before the 48 wave reductions, which would otherwise cost more than the HBM traffic.
@@ -433,3 +587,32 @@ extern "C" int mmi_sobel_add_bwd(const float* dt, int ldd, const float* chansum,
   MMI_CHECK_LAUNCH("mmi_sobel_add_bwd(2)");
   return mmi_pair_colsum(part, blocks1, C, dbias, dfactor, stream);  // partials[block][2][C] -> dbias (slot 0), dfactor (slot 1)
 }
+
+// ---- fused CEM forward: host side ------------------------------------------------------------------------------------
+// Statistics pre-pass of BN2: conv2 recomputed, nothing stored, partials[blocks][2][24] (blocks = mmi_cem_blocks).
+extern "C" int mmi_cem_blocks(int N, int H, int W) { return N * cdiv(H, TS) * cdiv(W, TS); }
+
+extern "C" int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_partials, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(x && w2 && stat_partials && N > 0 && H > 0 && W > 0 && ldx >= 3, "mmi_cem_conv2_stats: bad arguments");
+  const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
+  hipLaunchKernelGGL((smallconv_kernel<3, 24, false>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w2, (const float*)nullptr,
+                     (float*)nullptr, 24, stat_partials, H, W);
+  MMI_CHECK_LAUNCH("mmi_cem_conv2_stats");
+  return MMI_OK;
+}
+
+// x -> y3 (+ its statistics partials [blocks][2][3]) with y2, t, chansum written for the backward when non-NULL.
+extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const float* mean_invstd2, const float* gamma2,
+                                 const float* beta2, const float* factor, const float* sobel_bias, const float* w3, float* y2,
+                                 float* t, float* chansum, float* y3, float* stat_partials3, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(x && w2 && mean_invstd2 && gamma2 && beta2 && factor && sobel_bias && w3 && y3 && N > 0 && H > 0 && W > 0 && ldx >= 3,
+                "mmi_cem_fused_fwd: bad arguments");
+  MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0 && ((uintptr_t)t & 15) == 0, "mmi_cem_fused_fwd: y2 / t must be 16-byte aligned");
+  const CemOut out{y2, t, chansum, y3, stat_partials3};
+  const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
+  hipLaunchKernelGGL(cem_fused_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w2, mean_invstd2, gamma2, beta2, factor, sobel_bias,
+                     w3, out, ldx, H, W);
+  MMI_CHECK_LAUNCH("mmi_cem_fused_fwd");
+  return MMI_OK;
+}
+

@@ -922,3 +922,97 @@ class _SobelAdd(Function):
 
 def sobel_add(r, factor, bias):
     return _SobelAdd.apply(r, factor, bias)
+
+
+CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
+
+
+class _CemFused(Function):
+    """AdaptiveModule3 with the reference's stencil bank (models/common.py:751-803, 806-911) as ONE forward kernel behind a
+    statistics pre-pass: x -> conv2 -> BN2 + LeakyReLU -> r + stencil bank -> conv3 with r and t in LDS (csrc/cem.hip::
+    cem_fused_fwd_kernel), then BN3 + LeakyReLU + x.  y2, t and the channel-sum map are written on the way, so the backward
+    is the unfused chain's: BN3 backward, conv3 wgrad / dgrad, stencil-bank backward, BN2 backward, conv2 wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w2, g2, b2, rm2, rv2, nbt2, factor, sbias, w3, g3, b3, rm3, rv3, nbt3, training, eps, momentum):
+        x, ldx = rows_of(x)
+        w2, w3 = _ohwi(w2), _ohwi(w3)
+        n, h, w, _ = x.shape
+        dev, s = x.device, _stream()
+        rows = n * h * w
+        nblk = lib.cem_blocks(n, h, w)
+        f = factor.reshape(-1).contiguous()
+        mi2 = torch.empty(48, dtype=torch.float32, device=dev)
+        mi3 = torch.empty(6, dtype=torch.float32, device=dev)
+        if training:
+            part = scratch((nblk + 64) * 2 * 24, dev)
+            lib.cem_conv2_stats(x.data_ptr(), ldx, w2.data_ptr(), part.data_ptr(), n, h, w, s)
+            lib.bn_finalize(part.data_ptr(), nblk, rows, 24, eps, momentum, rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr(), mi2.data_ptr(), s)
+        else:
+            lib.bn_eval_stats(rm2.data_ptr(), rv2.data_ptr(), 24, eps, mi2.data_ptr(), s)
+        keep = torch.is_grad_enabled() or training
+        y2 = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
+        t = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
+        cs = torch.empty((n, h, w), dtype=torch.float32, device=dev) if keep else None
+        y3 = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+        part3 = scratch((nblk + 64) * 2 * 3, dev, slot=6) if training else None
+        lib.cem_fused_fwd(x.data_ptr(), ldx, w2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), f.data_ptr(), sbias.data_ptr(),
+                          w3.data_ptr(), y2.data_ptr() if keep else None, t.data_ptr() if keep else None, cs.data_ptr() if keep else None,
+                          y3.data_ptr(), part3.data_ptr() if training else None, n, h, w, s)
+        if training:
+            lib.bn_finalize(part3.data_ptr(), nblk, rows, 3, eps, momentum, rm3.data_ptr(), rv3.data_ptr(), nbt3.data_ptr(), mi3.data_ptr(), s)
+        else:
+            lib.bn_eval_stats(rm3.data_ptr(), rv3.data_ptr(), 3, eps, mi3.data_ptr(), s)
+        out = torch.empty_like(y3)
+        lib.bn_act_fwd(y3.data_ptr(), 3, mi3.data_ptr(), g3.data_ptr(), b3.data_ptr(), x.data_ptr(), ldx, out.data_ptr(), 3, rows, 3,
+                       ACT_LEAKY, s)
+        if keep:
+            ctx.save_for_backward(x, w2, y2, mi2, g2, b2, cs, f, t, w3, y3, mi3, g3, b3, sbias)
+        ctx.cfg = (n, h, w, ldx, training, tuple(factor.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w2, y2, mi2, g2, b2, cs, f, t, w3, y3, mi3, g3, b3, sbias = ctx.saved_tensors
+        n, h, w, ldx, training, fshape = ctx.cfg
+        dout, ldd = rows_of(dout)
+        dev, s = x.device, _stream()
+        rows, frozen = n * h * w, 0 if training else 1
+        # BN3 + LeakyReLU (+ the residual, whose gradient is dout itself)
+        dy3 = torch.empty_like(y3)
+        dg3, db3 = grad_like(g3), grad_like(b3)
+        _bn_act_bwd(y3, 3, dout, ldd, None, 0, 3, mi3, g3, b3, dy3, (dg3, db3, None, None), rows, 3, ACT_LEAKY, frozen, s)
+        # conv3: t (24) -> y3 (3)
+        d3 = ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3)
+        dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
+        dt = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
+        conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
+        # stencil bank
+        dr = torch.empty_like(dt)
+        df = torch.empty(24, dtype=torch.float32, device=dev)
+        dsb = grad_like(sbias)
+        nbytes = lib.sobel_add_bwd_workspace(n, h, w, 24)
+        ws = scratch(nbytes // 4 + 4, dev, slot=5)
+        lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr.data_ptr(), 24, df.data_ptr(), dsb.data_ptr(), ws.data_ptr(),
+                          n, h, w, 24, s)
+        # BN2 + LeakyReLU
+        dy2 = torch.empty_like(y2)
+        dg2, db2 = grad_like(g2), grad_like(b2)
+        _bn_act_bwd(y2, 24, dr, 24, None, 0, 24, mi2, g2, b2, dy2, (dg2, db2, None, None), rows, 24, ACT_LEAKY, frozen, s)
+        # conv2: x (3) -> y2 (24)
+        d2 = ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, ldx, 24)
+        dw2 = _wgrad(dy2, 24, x, ldx, w2, d2, overlap=OVERLAP_WGRAD)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+            conv_dgrad(dy2, w2, dx, ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, 3, 24), s)
+            lib.add(dx.data_ptr(), 3, dout.data_ptr(), ldd, dx.data_ptr(), 3, rows, 3, s)
+        if OVERLAP_WGRAD:
+            _join_side(dev)
+        return (dx, dw2, dg2, db2, None, None, None, df.view(fshape), dsb, dw3, dg3, db3, None, None, None, None, None, None)
+
+
+def cem_fused(x, w2, bn2, factor, sbias, w3, bn3):
+    return _CemFused.apply(x, w2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, factor, sbias, w3,
+                           bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, bn2.training, bn2.eps,
+                           bn2.momentum)

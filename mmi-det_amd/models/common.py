@@ -238,6 +238,11 @@ class AdaptiveModule3(nn.Module):
         self.relu3 = nn.LeakyReLU(0.1)
 
     def forward(self, x):
+        if (ops.CEM_FUSED and self.sobel.is_standard_bank() and x.dtype == torch.float32 and x.shape[-1] == 3
+                and self.bn2.training == self.bn3.training and self.bn2.eps == self.bn3.eps and self.bn2.momentum == self.bn3.momentum
+                and isinstance(self.relu2, nn.LeakyReLU) and self.relu2.negative_slope == 0.1):
+            # one forward kernel behind a statistics pre-pass (csrc/cem.hip::cem_fused_fwd_kernel)
+            return ops.cem_fused(x, self.conv2.weight, self.bn2, self.sobel.sobel_factor, self.sobel.bias, self.conv3.weight, self.bn3)
         w, b, rm, rv, nbt = _bn_args(self.bn2)
         r = ops.conv_bn_act(x, self.conv2.weight, w, b, rm, rv, nbt, 1, ACT_LEAKY, None, self.bn2.training, self.bn2.eps,
                             self.bn2.momentum)

@@ -81,3 +81,57 @@ def test_nonstandard_bank_falls_back_to_the_real_conv():
     assert not m.sobel.is_standard_bank()
     x = torch.rand(1, 8, 8, 3, device=dev())
     assert m(x).shape == x.shape
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 40), (1, 33, 17), (3, 5, 3), (1, 16, 16)])
+@pytest.mark.parametrize('train', [True, False])
+def test_fused_forward_matches_the_unfused_chain(shape, train, monkeypatch):
+    """csrc/cem.hip::cem_fused_fwd_kernel (x -> conv2 -> BN2 -> LeakyReLU -> stencil bank -> conv3 in one launch, r and t in LDS)
+    against the four-kernel chain it replaces, on tiles with ragged edges and on an image smaller than one tile: output, every
+    gradient and the BatchNorm running statistics.  Both are fp32 evaluations of the same sums in the same tap order, so the
+    tolerance is rounding of the BN affine form only."""
+    from mmidet_hip import ops
+    from models.common import AdaptiveModule3
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.rand(b, h, w, 3, generator=g).to(dev())
+    gy = torch.randn(b, h, w, 3, generator=g).to(dev())
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'CEM_FUSED', fused)
+        torch.manual_seed(5)
+        m = AdaptiveModule3(3, 3)
+        with torch.no_grad():
+            m.sobel.sobel_factor.uniform_(0.5, 1.5)
+            m.sobel.bias.normal_(0, 0.1)
+            for bn in (m.bn2, m.bn3):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.1)
+                bn.running_mean.normal_(0, 0.1)
+                bn.running_var.uniform_(0.5, 1.5)
+        m = m.to(dev()).train(train)
+        xg = x.clone().requires_grad_()
+        y = m(xg)
+        y.backward(gy)
+        res.append((y.detach(), xg.grad, {n: p.grad for n, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'tracked' in k}))
+    (y0, dx0, g0, s0), (y1, dx1, g1, s1) = res
+    close(y1, y0, what='out', tol=2e-6)
+    close(dx1, dx0, what='dx', tol=2e-5)
+    assert set(g0) == set(g1)
+    for n in g0:
+        close(g1[n], g0[n], what='d ' + n, tol=5e-5)
+    for k in s0:
+        close(s1[k].float(), s0[k].float(), what=k, tol=1e-6)
+
+
+def test_fused_forward_inference_keeps_nothing():
+    """Under no_grad in eval mode the fused kernel gets NULL for y2 / t / chansum: 1 read of x, 1 write of y3."""
+    from models.common import AdaptiveModule3
+    torch.manual_seed(1)
+    m = AdaptiveModule3(3, 3).to(dev()).eval()
+    x = torch.rand(2, 37, 29, 3, device=dev())
+    with torch.no_grad():
+        a = m(x)
+    b = m(x)
+    assert torch.equal(a, b)
