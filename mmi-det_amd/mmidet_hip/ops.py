@@ -950,7 +950,7 @@ class _CemFused(Function):
             lib.bn_finalize(part.data_ptr(), nblk, rows, 24, eps, momentum, rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr(), mi2.data_ptr(), s)
         else:
             lib.bn_eval_stats(rm2.data_ptr(), rv2.data_ptr(), 24, eps, mi2.data_ptr(), s)
-        keep = torch.is_grad_enabled() or training
+        keep = any(ctx.needs_input_grad)      # (grad mode itself is off inside forward)
         y2 = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
         t = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
         cs = torch.empty((n, h, w), dtype=torch.float32, device=dev) if keep else None
