@@ -8,6 +8,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int TS = 16;  // 16x16 pixel tile per 256-thread workgroup
 
 // out[pix][o] = sum_{tap,c} in[pix + tap - 1][c] * Wsel(o, tap, c)  (+ bias[o]); 3x3, stride 1, zero pad 1, NHWC.
@@ -270,6 +272,7 @@ struct CemOut {
   float* y3;
   float* stat_part;
 };
+template <int OB>
 __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restrict__ px, const float* __restrict__ pw2,
                                                             const float* __restrict__ pmi2, const float* __restrict__ pg2,
                                                             const float* __restrict__ pb2, const float* __restrict__ pfactor,
@@ -294,46 +297,83 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
     xs[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
   }
   __syncthreads();
-  // ---- r = LeakyReLU(BN2(conv2(x))) on the 20x20 region; zero outside the image
+  // ---- r = LeakyReLU(BN2(conv2(x))) on the 20x20 region; zero outside the image.  A thread owns TWO positions (q, q + 200)
+  // and keeps their accumulators as the halves of float2 registers: every FMA is a v_pk_fma_f32 whose weight operand is one
+  // SGPR broadcast to both halves, i.e. twice the fp32 VALU rate of the scalar form, and the 648 weights are fetched once
+  // for two pixels.  Per-position sums keep the tap-major / channel-minor order of smallconv_kernel<3, 24>.
+  if (t < RS * RS / 2) {
+    int qq[2];
+    bool in[2], interior[2];
+    f32x2 xin[27];                       // the two positions' 3x3x3 input patches, position h in half h
+    {
+      const float* sp[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        qq[h] = t + h * (RS * RS / 2);
+        const int i = qq[h] / RS, j = qq[h] % RS, ih = h0 - 2 + i, iw = w0 - 2 + j;
+        in[h] = ih >= 0 && iw >= 0 && ih < H && iw < W;
+        interior[h] = in[h] && i >= 2 && i < RS - 2 && j >= 2 && j < RS - 2;
+        sp[h] = xs + (i * XS + j) * 3;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int off = ((tap / 3) * XS + tap % 3) * 3 + c;
+          xin[tap * 3 + c] = f32x2{sp[0][off], sp[1][off]};
+        }
+    }
+    const int64_t pix0 = ((int64_t)n * H + (h0 - 2 + qq[0] / RS)) * W + (w0 - 2 + qq[0] % RS);
+    const int64_t pix1 = ((int64_t)n * H + (h0 - 2 + qq[1] / RS)) * W + (w0 - 2 + qq[1] % RS);
+    f32x2 sum{0.f, 0.f};
+    // OB output channels per iteration: their OB*27 weights are one contiguous run of w2, fetched with scalar loads inside
+    // the iteration (the address depends on the loop variable, so nothing is hoisted and nothing spills)
 #pragma unroll 1
-  for (int q = t; q < RS * RS; q += 256) {
-    asm volatile("" ::: "memory");   // keeps the 648 uniform weight loads inside the iteration (hoisted they cost 256 VGPRs)
-    const int i = q / RS, j = q % RS, ih = h0 - 2 + i, iw = w0 - 2 + j;
-    const bool in = ih >= 0 && iw >= 0 && ih < H && iw < W;
-    float acc[24];
+    for (int o0 = 0; o0 < 24; o0 += OB) {
+      const float* wp = p.w2 + o0 * 27;
+      f32x2 acc[OB];
 #pragma unroll
-    for (int o = 0; o < 24; ++o) acc[o] = 0.f;
+      for (int k = 0; k < OB; ++k) acc[k] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* src = xs + ((i + tap / 3) * XS + j + tap % 3) * 3;
-      const float x0 = src[0], x1 = src[1], x2 = src[2];
+      for (int e = 0; e < 27; ++e)            // e = tap * 3 + c: the order of smallconv_kernel<3, 24>
 #pragma unroll
-      for (int o = 0; o < 24; ++o) {
-        acc[o] += x0 * p.w2[(o * 9 + tap) * 3 + 0];
-        acc[o] += x1 * p.w2[(o * 9 + tap) * 3 + 1];
-        acc[o] += x2 * p.w2[(o * 9 + tap) * 3 + 2];
+        for (int k = 0; k < OB; ++k) {
+          const float w = wp[k * 27 + e];
+          acc[k] += xin[e] * f32x2{w, w};
+        }
+      f32x2 v[OB];
+#pragma unroll
+      for (int k = 0; k < OB; ++k) {
+        const float m = p.mi2[o0 + k], is = p.mi2[24 + o0 + k], g = p.g2[o0 + k], be = p.b2[o0 + k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float z = (acc[k][h] - m) * is * g + be;
+          v[k][h] = in[h] ? (z > 0.f ? z : 0.1f * z) : 0.f;
+        }
+        rs[qq[0] * 24 + o0 + k] = v[k][0];
+        rs[qq[1] * 24 + o0 + k] = v[k][1];
+      }
+      if (p.y2 != nullptr) {
+#pragma unroll
+        for (int k = 0; k < OB; ++k) {
+          if (interior[0]) p.y2[pix0 * 24 + o0 + k] = acc[k][0];
+          if (interior[1]) p.y2[pix1 * 24 + o0 + k] = acc[k][1];
+        }
+      }
+      // channel sum with the grouping of chansum_kernel: ((c0 + c1) + (c2 + c3)) per group of four, groups added in order
+      if (OB == 4) {
+        sum += (v[0] + v[1]) + (v[2 % OB] + v[3 % OB]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < OB; ++k) sum += v[k];
       }
     }
-    const bool interior = in && i >= 2 && i < RS - 2 && j >= 2 && j < RS - 2;
-    if (interior && p.y2 != nullptr) {
-      float* dst = p.y2 + (((int64_t)n * H + ih) * W + iw) * 24;
-#pragma unroll
-      for (int o = 0; o < 24; o += 4) *reinterpret_cast<f32x4*>(dst + o) = f32x4{acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+    cs[qq[0]] = sum[0];
+    cs[qq[1]] = sum[1];
+    if (p.chansum != nullptr) {
+      if (interior[0]) p.chansum[pix0] = sum[0];
+      if (interior[1]) p.chansum[pix1] = sum[1];
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int o = 0; o < 24; o += 4) {
-      f32x4 v;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float z = (acc[o + k] - p.mi2[o + k]) * p.mi2[24 + o + k] * p.g2[o + k] + p.b2[o + k];
-        v[k] = in ? (z > 0.f ? z : 0.1f * z) : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(rs + q * 24 + o) = v;
-      sum += (v[0] + v[1]) + (v[2] + v[3]);      // (the grouping of chansum_kernel)
-    }
-    cs[q] = sum;
-    if (interior && p.chansum != nullptr) p.chansum[((int64_t)n * H + ih) * W + iw] = sum;
   }
   __syncthreads();
   // ---- t = r + factor * stencil(chansum) + bias on the 18x18 region; zero outside the image
@@ -363,7 +403,9 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
   // ---- y3 = conv3(t) on the 16x16 tile (tap-major, channel-minor: the order of smallconv_kernel<24,3>)
   const int ti = t >> 4, tj = t & 15, oh = h0 + ti, ow = w0 + tj;
   const bool live = oh < H && ow < W;
-  float a3[3] = {0.f, 0.f, 0.f};
+  // (even / odd input channels accumulate in the two halves of a float2 -- v_pk_fma_f32 with an SGPR pair of adjacent weights --
+  //  and are added at the end)
+  f32x2 a2[3] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll 1          // (fully unrolled, the 54 ds_read_b128 of the nine taps are all issued up front: 216 VGPRs)
   for (int tap = 0; tap < 9; ++tap) {
     const float* src = ts + ((ti + tap / 3) * TT + tj + tap % 3) * 24;
@@ -371,11 +413,14 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
     for (int c = 0; c < 24; c += 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int o = 0; o < 3; ++o) a3[o] += v[k] * p.w3[(o * 9 + tap) * 24 + c + k];
+      for (int o = 0; o < 3; ++o) {
+        const float* wp = p.w3 + (o * 9 + tap) * 24 + c;
+        a2[o] += f32x2{v[0], v[1]} * f32x2{wp[0], wp[1]};
+        a2[o] += f32x2{v[2], v[3]} * f32x2{wp[2], wp[3]};
+      }
     }
   }
+  const float a3[3] = {a2[0][0] + a2[0][1], a2[1][0] + a2[1][1], a2[2][0] + a2[2][1]};
   if (live) {
     float* dst = p.y3 + (((int64_t)n * H + oh) * W + ow) * 3;
     dst[0] = a3[0];
@@ -610,8 +655,17 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
   MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0 && ((uintptr_t)t & 15) == 0, "mmi_cem_fused_fwd: y2 / t must be 16-byte aligned");
   const CemOut out{y2, t, chansum, y3, stat_partials3};
   const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
-  hipLaunchKernelGGL(cem_fused_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w2, mean_invstd2, gamma2, beta2, factor, sobel_bias,
-                     w3, out, ldx, H, W);
+  static const int ob = [] {      // output channels of conv2 per scalar-weight fetch (A/B switch; 4 keeps chansum's grouping)
+    const char* e = getenv("MMIDET_CEM_OB");
+    const int v = e ? atoi(e) : 4;
+    return (v == 2 || v == 3 || v == 4) ? v : 4;
+  }();
+#define CEM_LAUNCH(OB_) hipLaunchKernelGGL(cem_fused_fwd_kernel<OB_>, grid, dim3(256), 0, (hipStream_t)stream, x, w2, mean_invstd2, gamma2, \
+                                           beta2, factor, sobel_bias, w3, out, ldx, H, W)
+  if (ob == 2) CEM_LAUNCH(2);
+  else if (ob == 3) CEM_LAUNCH(3);
+  else CEM_LAUNCH(4);
+#undef CEM_LAUNCH
   MMI_CHECK_LAUNCH("mmi_cem_fused_fwd");
   return MMI_OK;
 }
