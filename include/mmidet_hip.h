@@ -228,6 +228,11 @@ int mmi_copy2d(const float* in, int ldi, float* out, int ldo, int64_t rows, int 
 /* nearest x2 upsample (nn.Upsample in the YAML head) and its backward (sum of the 4 children) */
 int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int mmi_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* the same with dy read through a row stride (a channel slice of a Concat gradient) and, when skip != NULL, the gradient of
+ * the map's OTHER consumer added in the same pass: dx = sum4(dy) + skip.  Replaces the autograd engine's fan-out accumulation
+ * (an ATen add) where a head Conv output feeds both nn.Upsample and a later Concat (yolov5 PANet, YAML head). */
+int mmi_upsample2x_bwd_acc(const float* dy, int lddy, const float* skip, int ldskip, float* dx, int N, int H, int W, int C,
+                           void* stream);
 /* SPP (models/common.py:681-693): x (N,H,W,C) row stride ldx -> out[..,0:C]=x, [C:2C]=mp5, [2C:3C]=mp9, [3C:4C]=mp13
  * (row stride ldo >= 4C), computed as cascaded 5x5 stride-1 max-pools. */
 int mmi_spp_pool_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, void* stream);
@@ -290,6 +295,10 @@ int mmi_avgpool8_fwd(const float* x, int ldx, int N, int H, int W, int C, float*
                      void* stream);
 int mmi_avgpool8_bwd(const float* dpool, int64_t d_batch_stride, int d_ld, float* dx, int lddx, int N, int H, int W, int C,
                      void* stream);
+/* the same plus the gradient of the map's other consumer (Add2, models/common.py:924-935) when skip != NULL: dx = pool
+ * gradient + skip in one pass instead of a pool-gradient pass and an ATen accumulation. */
+int mmi_avgpool8_bwd_acc(const float* dpool, int64_t d_batch_stride, int d_ld, const float* skip, int ldskip, float* dx, int lddx,
+                         int N, int H, int W, int C, void* stream);
 /* out = x + F.interpolate(tok 8x8 -> HxW, bilinear, align_corners=False) (common.py:548-550, 1364-1366 fused with Add2
  * common.py:924-935); x may be NULL.  tok[n*tok_batch_stride + (i*8+j)*tok_ld + c]. */
 int mmi_upsample_add_fwd(const float* x, int ldx, const float* tok, int64_t tok_batch_stride, int tok_ld, float* out,

@@ -655,10 +655,10 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
   MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0 && ((uintptr_t)t & 15) == 0, "mmi_cem_fused_fwd: y2 / t must be 16-byte aligned");
   const CemOut out{y2, t, chansum, y3, stat_partials3};
   const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
-  static const int ob = [] {      // output channels of conv2 per scalar-weight fetch (A/B switch; 4 keeps chansum's grouping)
-    const char* e = getenv("MMIDET_CEM_OB");
-    const int v = e ? atoi(e) : 4;
-    return (v == 2 || v == 3 || v == 4) ? v : 4;
+  static const int ob = [] {      // output channels of conv2 per scalar-weight fetch (A/B switch: 2 and 3 measure alike -- 1.06 ms
+    const char* e = getenv("MMIDET_CEM_OB");   // at 16 x 640 x 640 -- and 4, which spills SGPRs, 1.09; 4 keeps chansum's grouping)
+    const int v = e ? atoi(e) : 2;
+    return (v == 2 || v == 3 || v == 4) ? v : 2;
   }();
 #define CEM_LAUNCH(OB_) hipLaunchKernelGGL(cem_fused_fwd_kernel<OB_>, grid, dim3(256), 0, (hipStream_t)stream, x, w2, mean_invstd2, gamma2, \
                                            beta2, factor, sobel_bias, w3, out, ldx, H, W)

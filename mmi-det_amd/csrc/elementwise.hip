@@ -110,7 +110,8 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
 }
 
 template <int V>
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ skip, int ldskip,
+                                      float* __restrict__ dx, int N, int H, int W, int C) {
   const int cv = C / V, Ho = 2 * H, Wo = 2 * W;
   const int64_t total = (int64_t)N * H * W * cv;
   GRID_STRIDE(e, total) {
@@ -120,15 +121,20 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
     t /= W;
     const int h = (int)(t % H);
     const int n = (int)(t / H);
-    const float* s00 = dy + (((int64_t)n * Ho + 2 * h) * Wo + 2 * w) * C + c;
-    const float* s10 = s00 + (int64_t)Wo * C;
-    float* dst = dx + (((int64_t)n * H + h) * W + w) * C + c;
+    const float* s00 = dy + (((int64_t)n * Ho + 2 * h) * Wo + 2 * w) * lddy + c;
+    const float* s10 = s00 + (int64_t)Wo * lddy;
+    const int64_t pix = ((int64_t)n * H + h) * W + w;
+    float* dst = dx + pix * C + c;
     if (V == 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(s00), b = *reinterpret_cast<const f32x4*>(s00 + C),
-                  cc = *reinterpret_cast<const f32x4*>(s10), d = *reinterpret_cast<const f32x4*>(s10 + C);
-      *reinterpret_cast<f32x4*>(dst) = (a + b) + (cc + d);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s00), b = *reinterpret_cast<const f32x4*>(s00 + lddy),
+                  cc = *reinterpret_cast<const f32x4*>(s10), d = *reinterpret_cast<const f32x4*>(s10 + lddy);
+      f32x4 r = (a + b) + (cc + d);
+      if (skip != nullptr) r = *reinterpret_cast<const f32x4*>(skip + pix * ldskip + c) + r;   // (the map's other consumer)
+      *reinterpret_cast<f32x4*>(dst) = r;
     } else {
-      dst[0] = (s00[0] + s00[C]) + (s10[0] + s10[C]);
+      float r = (s00[0] + s00[lddy]) + (s10[0] + s10[lddy]);
+      if (skip != nullptr) r = skip[pix * ldskip + c] + r;
+      dst[0] = r;
     }
   }
 }
@@ -393,16 +399,21 @@ extern "C" int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int
   return MMI_OK;
 }
 
-extern "C" int mmi_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
-  MMI_CHECK_ARG(dy && dx && N > 0 && C > 0 && H > 0 && W > 0, "mmi_upsample2x_bwd: bad arguments");
-  if (vec4(C, {}, {dy, dx}))
+extern "C" int mmi_upsample2x_bwd_acc(const float* dy, int lddy, const float* skip, int ldskip, float* dx, int N, int H, int W, int C,
+                                      void* stream) {
+  MMI_CHECK_ARG(dy && dx && N > 0 && C > 0 && H > 0 && W > 0 && lddy >= C && (!skip || ldskip >= C), "mmi_upsample2x_bwd: bad arguments");
+  if (vec4(C, {lddy, skip ? ldskip : 0}, {dy, dx, skip}))
     hipLaunchKernelGGL(upsample2x_bwd_kernel<4>, dim3(ew_blocks((int64_t)N * H * W * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, dy, dx, N, H, W, C);
+                       (hipStream_t)stream, dy, lddy, skip, ldskip, dx, N, H, W, C);
   else
     hipLaunchKernelGGL(upsample2x_bwd_kernel<1>, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0,
-                       (hipStream_t)stream, dy, dx, N, H, W, C);
+                       (hipStream_t)stream, dy, lddy, skip, ldskip, dx, N, H, W, C);
   MMI_CHECK_LAUNCH("mmi_upsample2x_bwd");
   return MMI_OK;
+}
+
+extern "C" int mmi_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+  return mmi_upsample2x_bwd_acc(dy, C, nullptr, 0, dx, N, H, W, C, stream);
 }
 
 extern "C" int mmi_spp_pool_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int C, void* stream) {

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void avgpool8_fwd_kernel(const float* __restri
   }
 }
 
-__global__ void avgpool8_bwd_kernel(const float* __restrict__ dp, int64_t dbs, int dld, float* __restrict__ dx, int lddx,
-                                    int N, int H, int W, int C) {
+__global__ void avgpool8_bwd_kernel(const float* __restrict__ dp, int64_t dbs, int dld, const float* __restrict__ skip,
+                                    int ldskip, float* __restrict__ dx, int lddx, int N, int H, int W, int C) {
   const int cv = C / 4;
   const int64_t total = (int64_t)N * H * W * cv;
   GRID_STRIDE(e, total) {
@@ -77,7 +77,9 @@ __global__ void avgpool8_bwd_kernel(const float* __restrict__ dp, int64_t dbs, i
         acc += *reinterpret_cast<const f32x4*>(dp + (int64_t)n * dbs + (int64_t)(oi * 8 + oj) * dld + c) * inv;
       }
     }
-    *reinterpret_cast<f32x4*>(dx + (((int64_t)n * H + h) * W + w) * lddx + c) = acc;
+    const int64_t pix = ((int64_t)n * H + h) * W + w;
+    if (skip != nullptr) acc = *reinterpret_cast<const f32x4*>(skip + pix * ldskip + c) + acc;   // (the map's other consumer)
+    *reinterpret_cast<f32x4*>(dx + pix * lddx + c) = acc;
   }
 }
 
@@ -406,14 +408,20 @@ extern "C" int mmi_avgpool8_fwd(const float* x, int ldx, int N, int H, int W, in
   return MMI_OK;
 }
 
-extern "C" int mmi_avgpool8_bwd(const float* dpool, int64_t d_batch_stride, int d_ld, float* dx, int lddx, int N, int H,
-                                int W, int C, void* stream) {
+extern "C" int mmi_avgpool8_bwd_acc(const float* dpool, int64_t d_batch_stride, int d_ld, const float* skip, int ldskip, float* dx,
+                                    int lddx, int N, int H, int W, int C, void* stream) {
   MMI_CHECK_ARG(dpool && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && lddx % 4 == 0 && d_ld % 4 == 0 &&
-                    d_batch_stride % 4 == 0, "mmi_avgpool8_bwd: bad arguments");
+                    d_batch_stride % 4 == 0 && (!skip || (ldskip >= C && ldskip % 4 == 0 && ((uintptr_t)skip & 15) == 0)),
+                "mmi_avgpool8_bwd: bad arguments");
   hipLaunchKernelGGL(avgpool8_bwd_kernel, dim3(ew_blocks((int64_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream,
-                     dpool, d_batch_stride, d_ld, dx, lddx, N, H, W, C);
+                     dpool, d_batch_stride, d_ld, skip, ldskip, dx, lddx, N, H, W, C);
   MMI_CHECK_LAUNCH("mmi_avgpool8_bwd");
   return MMI_OK;
+}
+
+extern "C" int mmi_avgpool8_bwd(const float* dpool, int64_t d_batch_stride, int d_ld, float* dx, int lddx, int N, int H,
+                                int W, int C, void* stream) {
+  return mmi_avgpool8_bwd_acc(dpool, d_batch_stride, d_ld, nullptr, 0, dx, lddx, N, H, W, C, stream);
 }
 
 extern "C" int mmi_upsample_add_fwd(const float* x, int ldx, const float* tok, int64_t tok_batch_stride, int tok_ld,

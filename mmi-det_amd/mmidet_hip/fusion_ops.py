@@ -419,11 +419,16 @@ def transformer_block(x, heads, ps, eps, params, training=True):
 
 
 class _PoolTokens(Function):
-    """AdaptiveAvgPool2d(8,8) of both streams written as one (B,128,C) token tensor (rgb tokens first)."""
+    """AdaptiveAvgPool2d(8,8) of both streams written as one (B,128,C) token tensor (rgb tokens first).
+    skip=True also returns the two maps themselves (see ops._ConvBnAct): their other consumer (Add2) takes those aliases, so its
+    gradient arrives here and is added inside the pool-gradient kernel -- one pass instead of a pass plus the autograd engine's
+    fan-out accumulation (an ATen add over a full map, 8 per step)."""
 
     @staticmethod
-    def forward(ctx, rgb, ir):
+    def forward(ctx, rgb, ir, skip):
+        ctx.set_materialize_grads(False)
         ctx.src = rgb.dtype                                  # (bf16 storage: the pooling kernels read fp32 for now)
+        rgb_in, ir_in = rgb, ir
         rgb, ld0 = rows_of(ops.raw_cast(rgb, torch.float32))
         ir, ld1 = rows_of(ops.raw_cast(ir, torch.float32))
         n, h, w, c = rgb.shape
@@ -432,22 +437,31 @@ class _PoolTokens(Function):
         lib.avgpool8_fwd(rgb.data_ptr(), ld0, n, h, w, c, tok.data_ptr(), 128 * c, c, s)
         lib.avgpool8_fwd(ir.data_ptr(), ld1, n, h, w, c, tok.data_ptr() + 4 * 64 * c, 128 * c, c, s)
         ctx.shape = (n, h, w, c)
-        return tok
+        return (tok, rgb_in, ir_in) if skip else tok
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_rgb=None, g_ir=None):
         n, h, w, c = ctx.shape
+        if g is None:
+            return g_rgb, g_ir, None
         g = g.contiguous()
         s = _stream()
-        d0 = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
-        d1 = torch.empty_like(d0)
-        lib.avgpool8_bwd(g.data_ptr(), 128 * c, c, d0.data_ptr(), c, n, h, w, c, s)
-        lib.avgpool8_bwd(g.data_ptr() + 4 * 64 * c, 128 * c, c, d1.data_ptr(), c, n, h, w, c, s)
-        return ops.raw_cast(d0, ctx.src), ops.raw_cast(d1, ctx.src)
+        outs = []
+        for i, gs in enumerate((g_rgb, g_ir)):
+            d = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+            lds = 0
+            if gs is not None:
+                gs, lds = rows_of(ops.raw_cast(gs, torch.float32))
+                if lds % 4 != 0 or gs.data_ptr() % 16 != 0:
+                    gs, lds = gs.contiguous(), c
+            lib.avgpool8_bwd_acc(g.data_ptr() + 4 * i * 64 * c, 128 * c, c, gs.data_ptr() if gs is not None else None, lds, d.data_ptr(), c,
+                                 n, h, w, c, s)
+            outs.append(ops.raw_cast(d, ctx.src))
+        return outs[0], outs[1], None
 
 
-def pool_tokens(rgb, ir):
-    return _PoolTokens.apply(rgb, ir)
+def pool_tokens(rgb, ir, skip=False):
+    return _PoolTokens.apply(rgb, ir, skip)
 
 
 class _SplitTokens(Function):

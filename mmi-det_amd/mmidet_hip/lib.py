@@ -85,6 +85,7 @@ _SIGS = {
     'mmi_copy2d': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_upsample2x': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample2x_bwd_acc': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'mmi_spp_pool_fwd': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_spp_pool_bwd': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_build_targets': (c_int, [P, c_int, P, c_int, c_int, P, c_float, P, P, P, P, P, P]),
@@ -108,6 +109,7 @@ _SIGS = {
                                           P]),
     'mmi_avgpool8_fwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int64, c_int, P]),
     'mmi_avgpool8_bwd': (c_int, [P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_avgpool8_bwd_acc': (c_int, [P, c_int64, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample_add_fwd': (c_int, [P, c_int, P, c_int64, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample_add_bwd': (c_int, [P, c_int, P, c_int64, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_ffm_highpass': (c_int, [P, P, c_int, c_int, c_uint64, P]),

@@ -762,8 +762,14 @@ def concat(xs):
 
 
 class _Upsample2x(Function):
+    """nearest x2.  skip=True also returns x itself (see _ConvBnAct): the map's other consumer (a later Concat of the PANet head)
+    takes that alias, so its gradient arrives here as `gskip` and is added inside the backward kernel instead of by the autograd
+    engine (an ATen add); the incoming gradient is read through its row stride (a channel slice of a Concat gradient)."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip):
+        ctx.set_materialize_grads(False)
+        x_in = x
         x, ld = rows_of(x)
         if ld != x.shape[-1]:
             x = x.contiguous()
@@ -771,19 +777,29 @@ class _Upsample2x(Function):
         y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
         (lib.upsample2x_bf16 if x.dtype == BF16 else lib.upsample2x)(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
-        return y
+        return (y, x_in) if skip else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gskip=None):
         n, h, w, c = ctx.shape
-        g = g.contiguous()
+        if g is None:
+            return gskip, None
         dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
-        (lib.upsample2x_bwd_bf16 if g.dtype == BF16 else lib.upsample2x_bwd)(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
-        return dx
+        if g.dtype == BF16:
+            g = g.contiguous()
+            lib.upsample2x_bwd_bf16(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
+            if gskip is not None:
+                gs, lds = rows_of(raw_cast(gskip, BF16))
+                lib.add_bf16(dx.data_ptr(), c, gs.data_ptr(), lds, dx.data_ptr(), c, _nrows(dx), c, _stream())
+            return dx, None
+        g, ldg = rows_of(g)
+        gs, lds = rows_of(gskip) if gskip is not None else (None, 0)
+        lib.upsample2x_bwd_acc(g.data_ptr(), ldg, gs.data_ptr() if gs is not None else None, lds, dx.data_ptr(), n, h, w, c, _stream())
+        return dx, None
 
 
-def upsample2x(x):
-    return _Upsample2x.apply(x)
+def upsample2x(x, skip=False):
+    return _Upsample2x.apply(x, skip)
 
 
 class _SppPool(Function):

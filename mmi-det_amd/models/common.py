@@ -51,6 +51,8 @@ class Conv(nn.Module):
         assert isinstance(self.act, nn.Identity), 'unsupported activation %r' % self.act
         return ACT_NONE
 
+    fan_skip = True      # (yolo_test.forward_once: a saved map with a second consumer is handed on as the alias)
+
     def forward(self, x, residual=None, skip=False, dest=None):
         """skip=True: also return x as a second output (the Bottleneck shortcut, see ops._ConvBnAct); dest=(ops.Dest, channel):
         write the output into that channel slice of a wider buffer."""
@@ -330,12 +332,19 @@ class GPT(nn.Module):
         x = self.trans_blocks(x)
         return F2.layernorm(x, self.ln_f.weight, self.ln_f.bias, self.ln_f.eps)
 
-    def forward(self, x):
+    fan_skip = True      # forward(x, skip=True) -> (output, [rgb alias, ir alias]) for the maps' other consumers (yolo_test.forward_once)
+
+    def forward(self, x, skip=False):
         rgb, ir = x[0], x[1]
         assert rgb.shape[0] == ir.shape[0]
-        y = self._transform(F2.pool_tokens(rgb, ir))
+        pooled = F2.pool_tokens(rgb, ir, skip)
+        alias = None
+        if skip:
+            pooled, *alias = pooled
+        y = self._transform(pooled)
         a, b = F2.split_tokens(y)
-        return FusedTokens(a, b, tuple(rgb.shape[1:3]))
+        out = FusedTokens(a, b, tuple(rgb.shape[1:3]))
+        return (out, alias) if skip else out
 
 
 class GPT1_fourier(GPT):
@@ -349,11 +358,14 @@ class GPT1_fourier(GPT):
         self.sig = nn.Sigmoid()
         self.conv2 = _holder_conv(8, d_model, 1, 1)
 
-    def forward(self, x):
+    def forward(self, x, skip=False):
         rgb, ir = x[0], x[1]
         assert rgb.shape[0] == ir.shape[0]
         bs, c = rgb.shape[0], rgb.shape[-1]
-        pooled = F2.pool_tokens(rgb, ir)                                     # (B,128,C): rgb tokens then ir tokens
+        pooled = F2.pool_tokens(rgb, ir, skip)                               # (B,128,C): rgb tokens then ir tokens
+        alias = None
+        if skip:
+            pooled, *alias = pooled
         gate = F2.sigmoid(ops.conv_bias(pooled, self.conv1.weight.view(8, c), None, 1))   # (B,128,8)
         with torch.no_grad():                                                # pattern loss: value only
             hi = F2.ffm_highpass_mul(pooled.detach().view(bs * 2, 64, c))
@@ -364,7 +376,8 @@ class GPT1_fourier(GPT):
         y = self._transform(F2.mul(pt, pooled))
         self.last_tokens = y.detach()
         a, b = F2.split_tokens(y)
-        return FusedTokens(a, b, tuple(rgb.shape[1:3])), self.pattenLoss
+        out = FusedTokens(a, b, tuple(rgb.shape[1:3]))
+        return ((out, self.pattenLoss), alias) if skip else (out, self.pattenLoss)
 
 
 class RecContrastiveLoss(nn.Module):

@@ -40,9 +40,11 @@ def _tensors_of(obj):
 class Upsample2x(nn.Upsample):
     """nn.Upsample(None, 2, 'nearest') of the YAML head, on NHWC."""
 
-    def forward(self, x):
+    fan_skip = True
+
+    def forward(self, x, skip=False):
         assert self.mode == 'nearest' and float(self.scale_factor) == 2.0
-        return ops.upsample2x(x)
+        return ops.upsample2x(x, skip)
 
 
 class Detect(nn.Module):
@@ -135,6 +137,20 @@ class Model(nn.Module):
             srcs.append(src)
         self._lanes, self._srcs = lanes, srcs
         self._ir_streams = {}
+        # Fan-out plan: a saved map with exactly two consumers whose FIRST consumer can hand its input on (`fan_skip`: Conv, the
+        # fusion transformers' token pooling, nn.Upsample) is consumed as (output, alias) there; the second consumer reads the
+        # alias, so its gradient reaches the first consumer's backward as a second incoming gradient and is added inside that
+        # kernel (dgrad epilogue / pool gradient / upsample gradient) instead of by the autograd engine's ATen add.
+        cons = {}
+        for m in self.model:
+            for j in srcs[m.i]:
+                cons.setdefault(j, []).append(m.i)
+        self._fan_skip = {}
+        for j, c in cons.items():
+            first = self.model[c[0]]
+            if len(c) == 2 and c[0] != c[1] and getattr(first, 'fan_skip', False) and os.environ.get('MMIDET_FAN_SKIP', '1') != '0':
+                if isinstance(first.f, int) or isinstance(first, GPT):
+                    self._fan_skip.setdefault(c[0], []).append(j)
 
     def __getstate__(self):
         """Pickling (train.py:881-899 stores whole model objects) and deepcopy (ModelEMA): HIP stream handles stay behind."""
@@ -144,7 +160,7 @@ class Model(nn.Module):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        if '_lanes' not in state:            # an object written by the reference: same modules, none of the launch plan
+        if '_lanes' not in state or '_fan_skip' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
             self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
             self._plan_lanes()
 
@@ -203,6 +219,7 @@ class Model(nn.Module):
             done = {}
         x = self.Enhance(x)                                        # CEM on the RGB stream only
         bf16 = getattr(self, 'storage', 'f32') == 'bf16'
+        fan = self._fan_skip if torch.is_grad_enabled() else {}
         y = []
         prev = x
         for m in self.model:
@@ -224,12 +241,25 @@ class Model(nn.Module):
                     x = ops.cast(x, torch.bfloat16)
             elif isinstance(m, GPT1_fourier):
                 in_rgb, in_ir = x[0], x[1]
-                x, pt = m(x)
+                if m.i in fan:
+                    (x, pt), alias = m(x, skip=True)
+                    for j, a in zip(self._srcs[m.i], alias):
+                        y[j] = a
+                else:
+                    x, pt = m(x)
                 with torch.no_grad():                              # CBM + IGM: values only (detached in the reference)
                     st = F2.fusion_stats(in_rgb, in_ir, m.last_tokens)
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
-                x = m(x)
+                if m.i in fan:                                     # (output, alias of the input for its second consumer)
+                    x, alias = m(x, skip=True)
+                    if isinstance(alias, (list, tuple)):
+                        for j, a in zip(self._srcs[m.i], alias):
+                            y[j] = a
+                    else:
+                        y[self._srcs[m.i][0]] = alias
+                else:
+                    x = m(x)
                 if bf16 and m.i == 0:
                     x = ops.cast(x, torch.bfloat16)          # behind the RGB stem (Focus): everything downstream is bf16
             if lanes:
@@ -262,6 +292,7 @@ class Model(nn.Module):
                 m.conv = fuse_conv_and_bn(m.conv, m.bn)
                 delattr(m, 'bn')
                 m.forward = m.fuseforward
+        self._fan_skip = {}                                        # (fuseforward has no hand-on form; inference does not need one)
         self.info()
         return self
 

@@ -301,3 +301,48 @@ def test_transformer_block_dropout_matches_unfused_kernels():
     for n, a, b in zip(names, fused, [xu.grad] + [p.grad for p in prm]):
         if n != 'bk':                   # (true gradient 0, see above)
             close(a, b, tol=1e-4, what=n)
+
+
+@pytest.mark.parametrize('hw,C', [((40, 24), 32), ((20, 20), 64)])
+def test_fan_out_skip_forms_add_the_second_gradient_in_kernel(hw, C):
+    """pool_tokens(skip=True) and upsample2x(skip=True) hand their input on as an alias; the gradient of the alias' consumer is
+    added inside the backward kernel (mmi_avgpool8_bwd_acc / mmi_upsample2x_bwd_acc, the latter reading a channel SLICE of a
+    concat gradient through its row stride).  Same numbers as letting autograd accumulate: a + b is one rounding either way."""
+    from mmidet_hip import fusion_ops as F2
+    from mmidet_hip import ops
+    H, W = hw
+    d = dev()
+    g = torch.Generator().manual_seed(H + C)
+    rgb, ir = torch.randn(2, H, W, C, generator=g).to(d), torch.randn(2, H, W, C, generator=g).to(d)
+    gt = torch.randn(2, 128, C, generator=g).to(d)
+    ga, gb = torch.randn(2, H, W, C, generator=g).to(d), torch.randn(2, H, W, C, generator=g).to(d)
+    res = []
+    for skip in (False, True):
+        r, i = rgb.clone().requires_grad_(), ir.clone().requires_grad_()
+        if skip:
+            tok, ra, ia = F2.pool_tokens(r, i, True)
+        else:
+            tok, ra, ia = F2.pool_tokens(r, i), r, i
+        ((tok * gt).sum() + (ops.add(ra, ia) * ga).sum() + (ra * gb).sum()).backward()
+        res.append((tok.detach(), r.grad, i.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    close(res[1][1], res[0][1], what='d rgb', tol=1e-6)
+    close(res[1][2], res[0][2], what='d ir', tol=1e-6)
+    # upsample: the incoming gradient is the middle channel slice of a wider (concat) gradient
+    x = torch.randn(2, H, W, C, generator=g).to(d)
+    other = torch.randn(2, 2 * H, 2 * W, C // 2, generator=g).to(d)
+    gcat = torch.randn(2, 2 * H, 2 * W, C + C // 2, generator=g).to(d)
+    gx = torch.randn(2, H, W, C, generator=g).to(d)
+    res = []
+    for skip in (False, True):
+        xg = x.clone().requires_grad_()
+        if skip:
+            up, xa = ops.upsample2x(xg, True)
+        else:
+            up, xa = ops.upsample2x(xg), xg
+        cat = ops.concat([other, up])
+        ((cat * gcat).sum() + (xa * gx).sum()).backward()
+        res.append(xg.grad)
+    ref = F.avg_pool2d(nchw(gcat[..., C // 2:]), 2) * 4 + nchw(gx)
+    close(nchw(res[1]), ref, what='upsample dx vs torch', tol=1e-6)
+    close(res[1], res[0], what='upsample dx', tol=1e-6)

@@ -516,3 +516,44 @@ def test_rectangular_image_matches_oracle():
     close(cg, co, what='Combine_loss', tol=1e-4)
     close(m.model[1].conv.weight.grad, o.model[1].conv.weight.grad, what='dW(model.1.conv)', tol=2e-3)
     close(m.model[6].conv1.weight.grad, o.model[6].conv1.weight.grad, what='dW(FFM conv1)', tol=2e-3)
+
+
+def test_fan_out_plan_replaces_engine_accumulation_bit_for_bit():
+    """Model._fan_skip (yolo_test._plan_lanes): the 16 saved maps with two consumers are handed on as aliases by their first
+    consumer, whose backward kernel adds the second consumer's gradient.  With the plan switched off the autograd engine does the
+    same additions with ATen kernels; every one is a two-term sum, so the two steps agree bit for bit."""
+    import yaml
+    from models.yolo_test import Model
+    from oracle import portable_init
+    from utils.loss import ComputeLoss
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, '..', 'mmi-det_amd', 'models', 'transformer', 'yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml')) as f:
+        cfg = yaml.safe_load(f)
+    cfg['nc'] = 6
+    cfg['depth_multiple'], cfg['width_multiple'] = 0.33, 0.25
+    imgs, targets = portable_init.synth_batch(2, 256, 6, per_image=6, seed=5)
+    x = (imgs.float() / 255).to(dev())
+    grads = []
+    for plan in (True, False):
+        torch.manual_seed(0)
+        m = Model(cfg).to(dev())
+        m.load_state_dict(portable_init.fill_(m.state_dict()))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.nc, m.gr = 6, 1.0
+        from oracle.ref_loss import scaled_hyp
+        m.hyp = scaled_hyp(6, 256)
+        m.train()
+        assert len(m._fan_skip) >= 10 and sum(len(v) for v in m._fan_skip.values()) == 16
+        if not plan:
+            m._fan_skip = {}
+        pred, comb = m(x[:, :3], x[:, 3:])
+        loss, _ = ComputeLoss(m)(pred, targets.to(dev()), comb.reshape(-1))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert set(grads[0]) == set(grads[1])
+    exact = sum(int(torch.equal(grads[0][n], grads[1][n])) for n in grads[0])
+    for n in grads[0]:
+        close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=1e-6)
