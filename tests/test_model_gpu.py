@@ -522,15 +522,11 @@ def test_fan_out_plan_replaces_engine_accumulation_bit_for_bit():
     """Model._fan_skip (yolo_test._plan_lanes): the 16 saved maps with two consumers are handed on as aliases by their first
     consumer, whose backward kernel adds the second consumer's gradient.  With the plan switched off the autograd engine does the
     same additions with ATen kernels; every one is a two-term sum, so the two steps agree bit for bit."""
-    import yaml
     from models.yolo_test import Model
     from oracle import portable_init
     from utils.loss import ComputeLoss
-    here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, '..', 'mmi-det_amd', 'models', 'transformer', 'yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml')) as f:
-        cfg = yaml.safe_load(f)
+    cfg = tiny_cfg('fourier')
     cfg['nc'] = 6
-    cfg['depth_multiple'], cfg['width_multiple'] = 0.33, 0.25
     imgs, targets = portable_init.synth_batch(2, 256, 6, per_image=6, seed=5)
     x = (imgs.float() / 255).to(dev())
     grads = []
