@@ -518,10 +518,12 @@ def test_rectangular_image_matches_oracle():
     close(m.model[6].conv1.weight.grad, o.model[6].conv1.weight.grad, what='dW(FFM conv1)', tol=2e-3)
 
 
-def test_fan_out_plan_replaces_engine_accumulation_bit_for_bit():
+def test_fan_out_plan_replaces_engine_accumulation():
     """Model._fan_skip (yolo_test._plan_lanes): the 16 saved maps with two consumers are handed on as aliases by their first
     consumer, whose backward kernel adds the second consumer's gradient.  With the plan switched off the autograd engine does the
-    same additions with ATen kernels; every one is a two-term sum, so the two steps agree bit for bit."""
+    same additions with ATen kernels.  The sums are the same; where the first consumer is a 1x1 Conv the second gradient joins the
+    accumulator in the GEMM epilogue, i.e. at another place of the rounding sequence, so the two steps agree to fp32 rounding
+    carried through the depth of the graph (measured 2e-6 on the first layer's weight gradient), not bit for bit."""
     from models.yolo_test import Model
     from oracle import portable_init
     from utils.loss import ComputeLoss
@@ -552,4 +554,4 @@ def test_fan_out_plan_replaces_engine_accumulation_bit_for_bit():
     assert set(grads[0]) == set(grads[1])
     exact = sum(int(torch.equal(grads[0][n], grads[1][n])) for n in grads[0])
     for n in grads[0]:
-        close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=1e-6)
+        close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=2e-5)
