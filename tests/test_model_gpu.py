@@ -554,4 +554,6 @@ def test_fan_out_plan_replaces_engine_accumulation():
     assert set(grads[0]) == set(grads[1])
     exact = sum(int(torch.equal(grads[0][n], grads[1][n])) for n in grads[0])
     for n in grads[0]:
+        if n.endswith('key_proj.bias'):      # (its true gradient is zero -- softmax is shift-invariant -- so what is there is noise)
+            continue
         close(grads[0][n], grads[1][n], what=n + ' (%d of %d tensors bit-identical)' % (exact, len(grads[0])), tol=2e-4)
