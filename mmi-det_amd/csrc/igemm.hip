@@ -860,6 +860,7 @@ struct WgradP {
   // split-K fold inside the launch: per-tile arrival counters (zero before and after); the workgroup that completes a
   // tile's last split sums the splits' partial tiles in split order (deterministic) into DW (and DB): no reduce launch
   int* cnt;
+  int cnt_per_tile;  // counters of one tile: sum over the tree's levels of ceil(nodes / 4)
   float* DW;
   float* DB;
   // TAB loaders: the per-pixel {source offset, invalid-tap mask} table of the layer's geometry, precomputed once
@@ -1278,56 +1279,76 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     }
   }
   if (!fold) return;
-  // ---- the last split of this tile to finish folds all of them, in split order ----
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's (write-through) stores have completed
-  __syncthreads();
-  if (t == 0) {
-    const int last = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.splits - 1;
-    if (last) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fold_flag = last;
-  }
-  __syncthreads();
-  if (!fold_flag) return;
-  // one 32x32 sub-tile at a time (16 values per lane); four splits' loads in flight together, summed in split order
+  // ---- split-K fold inside the launch, as a tree of fan-in 4 ------------------------------------------------------------
+  // Level 0 holds the splits' slabs.  At every level the members of a group of four consecutive nodes arrive on the group's
+  // counter; the last one sums the group (in node order: deterministic) into the slab of the group's first member -- which
+  // becomes the node of the next level -- and goes on to arrive there; the group that is alone at its level writes dW (and
+  // dbias) instead.  A fold therefore never reads more than four slabs, whatever the split count (one workgroup walking a
+  // long list serially was 2x slower than the separate reduce launch: profiles/r02_wgrad_fold_microbench.txt), and the
+  // folds of different groups run on different workgroups.  Counters: p.cnt + tile * p.cnt_per_tile, level after level.
+  int node = split, nodes = p.splits, stride = 1;          // stride: slab distance between neighbouring nodes of this level
+  int* cnt = p.cnt + (int64_t)tile * p.cnt_per_tile;
+  while (true) {
+    const int group = node >> 2, gfirst = group << 2, gsize = min(4, nodes - gfirst);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's (write-through) stores have completed
+    __syncthreads();
+    if (t == 0) {
+      const int last = __hip_atomic_fetch_add(cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+      if (last) __hip_atomic_store(cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fold_flag = last;
+    }
+    __syncthreads();
+    if (!fold_flag) return;
+    const bool root = nodes <= 4;
+    const int64_t z0 = (int64_t)gfirst * stride;             // slab of the group's first member (and of its sum)
+    // one 32x32 sub-tile at a time (16 values per lane); the group's loads in flight together, summed in node order
 #pragma unroll 1
-  for (int ij = 0; ij < TM * TN; ++ij) {
-    const int i = ij / TN, j = ij - i * TN;
-    const int col = n0 + wn * WN + j * 32 + l31;
-    const int rbase = m0 + wm * WM + i * 32 + 4 * lh;
-    if (col >= p.Ntot) continue;
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = 0.f;
-    const int64_t e0 = (int64_t)rbase * p.Ntot + col;
-#pragma unroll 1
-    for (int z = 0; z < p.splits; z += 4) {
+    for (int ij = 0; ij < TM * TN; ++ij) {
+      const int i = ij / TN, j = ij - i * TN;
+      const int col = n0 + wn * WN + j * 32 + l31;
+      const int rbase = m0 + wm * WM + i * 32 + 4 * lh;
+      if (col >= p.Ntot) continue;
+      const int64_t e0 = (int64_t)rbase * p.Ntot + col;
       float u[4][16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float* part = p.OUT + (int64_t)min(z + q, p.splits - 1) * p.slab_stride + e0;
+        const float* part = p.OUT + (z0 + (int64_t)min(q, gsize - 1) * stride) * p.slab_stride + e0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
           u[q][r] = rbase + dr < p.Cout ? ld_agent(part + (int64_t)dr * p.Ntot) : 0.f;
         }
       }
+      float v[16];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (z + q < p.splits) {
+      for (int r = 0; r < 16; ++r) v[r] = u[0][r];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (q < gsize) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += u[q][r];
         }
-    }
+      float* dst = root ? p.DW + e0 : p.OUT + z0 * p.slab_stride + e0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);
-      if (rbase + dr < p.Cout) p.DW[e0 + (int64_t)dr * p.Ntot] = v[r];
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (rbase + dr < p.Cout) {
+          if (root) dst[(int64_t)dr * p.Ntot] = v[r];
+          else st_agent(dst + (int64_t)dr * p.Ntot, v[r]);
+        }
+      }
     }
-  }
-  if (want_bias && t < BM && m0 + t < p.Cout) {
-    float s = 0.f;
-    for (int z = 0; z < p.splits; ++z) s += ld_agent(p.OUTB + (int64_t)z * p.slab_stride + m0 + t);
-    p.DB[m0 + t] = s;
+    if (want_bias && t < BM && m0 + t < p.Cout) {
+      float sb = 0.f;
+      for (int q = 0; q < gsize; ++q) sb += ld_agent(p.OUTB + (z0 + (int64_t)q * stride) * p.slab_stride + m0 + t);
+      if (root) p.DB[m0 + t] = sb;
+      else st_agent(p.OUTB + z0 * p.slab_stride + m0 + t, sb);
+    }
+    if (root) return;
+    cnt += (nodes + 3) >> 2;          // next level's counters follow this level's
+    node = group;
+    nodes = (nodes + 3) >> 2;
+    stride <<= 2;
   }
 }
 
@@ -2006,12 +2027,17 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   // The fold runs on ONE workgroup per tile, serially over the splits (a dependent round of loads per four of them), while
   // the reduce kernel spreads the same reads over the whole chip: measured (profiles/r02_wgrad_fold_microbench.txt) the fold
   // only wins up to a handful of splits, so long split lists keep the separate reduce launch.
-  static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 4;
-  const bool fold = g.splits > 1 && g.splits <= fold_max && g.mtiles * g.ntiles <= WG_MAX_TILES && !fold_off;
+  // (round 2, first form: one workgroup per tile walking all splits -- it only won up to four of them,
+  //  profiles/r02_wgrad_fold_microbench.txt; the tree of fan-in 4 in the kernel's epilogue has no such limit)
+  static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 256;
+  int cnt_per_tile = 0;
+  for (int n = g.splits; n > 1; n = (n + 3) / 4) cnt_per_tile += (n + 3) / 4;
+  const bool fold = g.splits > 1 && g.splits <= fold_max && (int64_t)g.mtiles * g.ntiles * cnt_per_tile <= WG_MAX_TILES && !fold_off;
   WgradP p{};
   p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? slabs : dw;
   p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? slabs + wsize : dbias);
   p.cnt = fold ? (int*)workspace : nullptr;
+  p.cnt_per_tile = cnt_per_tile;
   p.DW = dw; p.DB = dbias;
   p.zero = zero_src();
   if (p.zero == nullptr) {
