@@ -2027,9 +2027,12 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   // The fold runs on ONE workgroup per tile, serially over the splits (a dependent round of loads per four of them), while
   // the reduce kernel spreads the same reads over the whole chip: measured (profiles/r02_wgrad_fold_microbench.txt) the fold
   // only wins up to a handful of splits, so long split lists keep the separate reduce launch.
-  // (round 2, first form: one workgroup per tile walking all splits -- it only won up to four of them,
-  //  profiles/r02_wgrad_fold_microbench.txt; the tree of fan-in 4 in the kernel's epilogue has no such limit)
-  static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 256;
+  // Measured twice (profiles/r02_wgrad_fold_microbench.txt: one workgroup walking all splits; profiles/r02_ab_wgrad_fold_tree.txt:
+  // the fan-in-4 tree of the kernel's epilogue): the in-launch fold wins up to FOUR splits (one level of the tree) and loses
+  // beyond -- every level is a dependent round of device-coherent loads of slabs written on other XCDs (~6 us), against one
+  // chip-wide reduce launch that streams them: 3x3 128->128@80x80 0.266 -> 0.351 ms, the step 123.2 -> 125.3 ms with the tree
+  // for every split count.  So longer split lists keep the separate reduce launch; MMIDET_WGRAD_FOLD_MAX (<= 256) moves the limit.
+  static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 4;
   int cnt_per_tile = 0;
   for (int n = g.splits; n > 1; n = (n + 3) / 4) cnt_per_tile += (n + 3) / 4;
   const bool fold = g.splits > 1 && g.splits <= fold_max && (int64_t)g.mtiles * g.ntiles * cnt_per_tile <= WG_MAX_TILES && !fold_off;
