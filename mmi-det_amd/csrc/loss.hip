@@ -186,13 +186,18 @@ __global__ __launch_bounds__(256) void loss_scatter_kernel(LossP P) {
         if (k != 4) dps[k] = g[(int64_t)r * no + k];
       continue;
     }
-    for (int k = 0; k < no; ++k) {
-      if (k == 4) continue;
-      float s = 0.f;
-      for (int q = 0; q <= r; ++q)
-        if (cid[q] == cell) s += g[(int64_t)q * no + k];
-      dps[k] = s;
-    }
+    // a shared cell (rare): ONE scan over the earlier records -- the cell's gradient row is the accumulator, every column sums
+    // its terms in increasing record order starting from 0 (the same sequence of additions as a per-column scan, which cost
+    // `no` scans of up to n records per shared cell: 0.5 ms per step)
+    for (int k = 0; k < no; ++k)
+      if (k != 4) dps[k] = 0.f;
+    int left = P.cnt[l][cell];
+    for (int q = 0; q <= r && left > 0; ++q)
+      if (cid[q] == cell) {
+        --left;
+        for (int k = 0; k < no; ++k)
+          if (k != 4) dps[k] += g[(int64_t)q * no + k];
+      }
   }
 }
 

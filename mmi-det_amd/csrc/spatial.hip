@@ -281,12 +281,16 @@ __global__ __launch_bounds__(256) void separation_loss_kernel(const float* __res
 __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
                                                            int ldb, const float* __restrict__ tok, int N, int H, int W, int C,
                                                            double* __restrict__ acc, unsigned int* __restrict__ hist) {
-  __shared__ unsigned int lh[3][256];
+  // 16 copies of every bin, one per lane residue, laid out [histogram][bin][copy]: the maps are post-activation values that
+  // crowd a few bins near zero, and 64 lanes adding to ONE LDS word serialise (the kernel ran at 0.12 of HBM for it); lanes of
+  // different residues now hit neighbouring banks instead of one address
+  constexpr int SUB = 16;
+  __shared__ unsigned int lh[3][256 * SUB];
   __shared__ double lacc[11];
-  for (int i = threadIdx.x; i < 768; i += 256) (&lh[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < 768 * SUB; i += 256) (&lh[0][0])[i] = 0u;
   if (threadIdx.x < 11) lacc[threadIdx.x] = 0.0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, sub = lane & (SUB - 1);
   const int64_t npix = (int64_t)N * H * W;
   const int cv = C / 4;
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -313,9 +317,9 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
       for (int k = 0; k < 4; ++k) {
         const float x = av[k], y = bv[k], f = fv[k];
         m[0] += x; m[1] += y; m[2] += f; m[3] += x * x; m[4] += y * y; m[5] += f * f; m[6] += x * f; m[7] += y * f;
-        if (x >= 0.f && x <= 1.f) atomicAdd(&lh[0][min((int)(x * 256.0f), 255)], 1u);
-        if (y >= 0.f && y <= 1.f) atomicAdd(&lh[1][min((int)(y * 256.0f), 255)], 1u);
-        if (f >= 0.f && f <= 1.f) atomicAdd(&lh[2][min((int)(f * 256.0f), 255)], 1u);
+        if (x >= 0.f && x <= 1.f) atomicAdd(&lh[0][min((int)(x * 256.0f), 255) * SUB + sub], 1u);
+        if (y >= 0.f && y <= 1.f) atomicAdd(&lh[1][min((int)(y * 256.0f), 255) * SUB + sub], 1u);
+        if (f >= 0.f && f <= 1.f) atomicAdd(&lh[2][min((int)(f * 256.0f), 255) * SUB + sub], 1u);
       }
       const f32x4 dp = av - bv;
       d0 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3];
@@ -352,7 +356,9 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.x < 11) atomicAdd(&acc[threadIdx.x], lacc[threadIdx.x]);
   for (int i = threadIdx.x; i < 768; i += 256) {
-    const unsigned int v = (&lh[0][0])[i];
+    unsigned int v = 0u;
+#pragma unroll
+    for (int k = 0; k < SUB; ++k) v += (&lh[0][0])[i * SUB + k];
     if (v) atomicAdd(&hist[i], v);
   }
 }
