@@ -281,63 +281,70 @@ __global__ __launch_bounds__(256) void separation_loss_kernel(const float* __res
 __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
                                                            int ldb, const float* __restrict__ tok, int N, int H, int W, int C,
                                                            double* __restrict__ acc, unsigned int* __restrict__ hist) {
-  // 16 copies of every bin, one per lane residue, laid out [histogram][bin][copy]: the maps are post-activation values that
-  // crowd a few bins near zero, and 64 lanes adding to ONE LDS word serialise (the kernel ran at 0.12 of HBM for it); lanes of
-  // different residues now hit neighbouring banks instead of one address
-  constexpr int SUB = 16;
-  __shared__ unsigned int lh[3][256 * SUB];
+  // (an LDS atomic costs its ~64 cycles per wave instruction whether or not the lanes collide -- 16 privatised copies of every
+  //  bin made the kernel slower, 403 -> 493 us -- so what counts is the NUMBER of atomic instructions: full waves, below)
+  __shared__ unsigned int lh[3][256];
   __shared__ double lacc[11];
-  for (int i = threadIdx.x; i < 768 * SUB; i += 256) (&lh[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < 768; i += 256) (&lh[0][0])[i] = 0u;
   if (threadIdx.x < 11) lacc[threadIdx.x] = 0.0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, sub = lane & (SUB - 1);
+  const int lane = threadIdx.x & 63;
   const int64_t npix = (int64_t)N * H * W;
   const int cv = C / 4;
+  // A wave covers 64 channel quads: with C < 256 that is several pixels side by side (C = 128 at P2: two), so that every
+  // vector -- and every LDS-atomic -- instruction works on full waves; lpp lanes per pixel, ppw pixels per wave.
+  const int lpp = cv >= 64 ? 64 : (cv > 16 ? 32 : (cv > 8 ? 16 : 8)), ppw = 64 / lpp;
+  const int sub = lane / lpp, ql = lane - sub * lpp;
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float cs[3] = {0.f, 0.f, 0.f};
   const int64_t img = (int64_t)H * W;
-  for (int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (int64_t)gridDim.x * 4) {
-    const int n = (int)(pix / img);
-    const int64_t rem = pix - (int64_t)n * img;
-    const int h = (int)(rem / W), w = (int)(rem % W);
-    int h0, h1, w0, w1;
-    float a0, a1, b0, b1;
-    bil_coef(h, H, h0, h1, a0, a1);
-    bil_coef(w, W, w0, w1, b0, b1);
-    const bool pair = n + 1 < N;
+  const int64_t wpix = (int64_t)gridDim.x * 4 * ppw;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw; base < npix; base += wpix) {
+    const int64_t pix = base + sub;
+    const bool live = pix < npix;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int q = lane; q < cv; q += 64) {
-      const int c = q * 4;
-      const f32x4 av = *reinterpret_cast<const f32x4*>(a + pix * lda + c);
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(b + pix * ldb + c);
-      const int64_t tb = (int64_t)n * 128 * C;
-      const f32x4 fv = 0.5f * (bil_sample(tok, tb, C, c, h0, h1, a0, a1, w0, w1, b0, b1) +
-                               bil_sample(tok, tb + 64 * (int64_t)C, C, c, h0, h1, a0, a1, w0, w1, b0, b1));
+    bool pair = false;
+    if (live) {
+      const int n = (int)(pix / img);
+      const int64_t rem = pix - (int64_t)n * img;
+      const int h = (int)(rem / W), w = (int)(rem % W);
+      int h0, h1, w0, w1;
+      float a0, a1, b0, b1;
+      bil_coef(h, H, h0, h1, a0, a1);
+      bil_coef(w, W, w0, w1, b0, b1);
+      pair = n + 1 < N;
+      for (int q = ql; q < cv; q += lpp) {
+        const int c = q * 4;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + pix * lda + c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + pix * ldb + c);
+        const int64_t tb = (int64_t)n * 128 * C;
+        const f32x4 fv = 0.5f * (bil_sample(tok, tb, C, c, h0, h1, a0, a1, w0, w1, b0, b1) +
+                                 bil_sample(tok, tb + 64 * (int64_t)C, C, c, h0, h1, a0, a1, w0, w1, b0, b1));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float x = av[k], y = bv[k], f = fv[k];
-        m[0] += x; m[1] += y; m[2] += f; m[3] += x * x; m[4] += y * y; m[5] += f * f; m[6] += x * f; m[7] += y * f;
-        if (x >= 0.f && x <= 1.f) atomicAdd(&lh[0][min((int)(x * 256.0f), 255) * SUB + sub], 1u);
-        if (y >= 0.f && y <= 1.f) atomicAdd(&lh[1][min((int)(y * 256.0f), 255) * SUB + sub], 1u);
-        if (f >= 0.f && f <= 1.f) atomicAdd(&lh[2][min((int)(f * 256.0f), 255) * SUB + sub], 1u);
-      }
-      const f32x4 dp = av - bv;
-      d0 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3];
-      if (pair) {
-        const f32x4 an = *reinterpret_cast<const f32x4*>(a + (pix + img) * lda + c);
-        const f32x4 bn = *reinterpret_cast<const f32x4*>(b + (pix + img) * ldb + c);
-        const f32x4 dn = av - bn, dm = an - bv;
-        d1 += dn[0] * dn[0] + dn[1] * dn[1] + dn[2] * dn[2] + dn[3] * dn[3];
-        d2 += dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2] + dm[3] * dm[3];
+        for (int k = 0; k < 4; ++k) {
+          const float x = av[k], y = bv[k], f = fv[k];
+          m[0] += x; m[1] += y; m[2] += f; m[3] += x * x; m[4] += y * y; m[5] += f * f; m[6] += x * f; m[7] += y * f;
+          if (x >= 0.f && x <= 1.f) atomicAdd(&lh[0][min((int)(x * 256.0f), 255)], 1u);
+          if (y >= 0.f && y <= 1.f) atomicAdd(&lh[1][min((int)(y * 256.0f), 255)], 1u);
+          if (f >= 0.f && f <= 1.f) atomicAdd(&lh[2][min((int)(f * 256.0f), 255)], 1u);
+        }
+        const f32x4 dp = av - bv;
+        d0 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3];
+        if (pair) {
+          const f32x4 an = *reinterpret_cast<const f32x4*>(a + (pix + img) * lda + c);
+          const f32x4 bn = *reinterpret_cast<const f32x4*>(b + (pix + img) * ldb + c);
+          const f32x4 dn = av - bn, dm = an - bv;
+          d1 += dn[0] * dn[0] + dn[1] * dn[1] + dn[2] * dn[2] + dn[3] * dn[3];
+          d2 += dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2] + dm[3] * dm[3];
+        }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = lpp >> 1; o > 0; o >>= 1) {       // sums over the pixel's own lanes
       d0 += __shfl_xor(d0, o);
       d1 += __shfl_xor(d1, o);
       d2 += __shfl_xor(d2, o);
     }
-    if (pair && lane == 0) {  // F.normalize(d, dim=1): d / max(|d|, 1e-12); sum_c of its square
+    if (pair && ql == 0) {  // F.normalize(d, dim=1): d / max(|d|, 1e-12); sum_c of its square
       const float n0 = fmaxf(sqrtf(d0), 1e-12f), n1 = fmaxf(sqrtf(d1), 1e-12f), n2 = fmaxf(sqrtf(d2), 1e-12f);
       cs[0] += d0 / (n0 * n0);
       cs[1] += d1 / (n1 * n1);
@@ -351,14 +358,17 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) atomicAdd(&lacc[k], (double)v);
   }
-  if (lane == 0)
-    for (int k = 0; k < 3; ++k) atomicAdd(&lacc[8 + k], (double)cs[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                     // (cs lives in the first lane of every pixel group)
+    float v = cs[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) atomicAdd(&lacc[8 + k], (double)v);
+  }
   __syncthreads();
   if (threadIdx.x < 11) atomicAdd(&acc[threadIdx.x], lacc[threadIdx.x]);
   for (int i = threadIdx.x; i < 768; i += 256) {
-    unsigned int v = 0u;
-#pragma unroll
-    for (int k = 0; k < SUB; ++k) v += (&lh[0][0])[i * SUB + k];
+    const unsigned int v = (&lh[0][0])[i];
     if (v) atomicAdd(&hist[i], v);
   }
 }
