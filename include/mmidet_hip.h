@@ -101,6 +101,9 @@ int mmi_set_uniform_loaders(int on);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
 int mmi_set_tile_override(int bm, int bn);
+/* tuning hook of the weight-gradient planner (tools/sweep_wgrad.py): force the tile variant (128/64 x 128/64; 0,0 = the planner's)
+ * and the split-K count of every following mmi_conv_wgrad* call; splits = 0 switches the override off. */
+int mmi_set_wgrad_override(int bm, int bn, int splits);
 size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d);
 int mmi_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stat_partials, void* workspace,
                  size_t workspace_bytes, const mmi_conv_desc* d, void* stream);

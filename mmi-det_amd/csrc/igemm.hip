@@ -1686,6 +1686,13 @@ extern "C" int mmi_set_tile_override(int bm, int bn) {
   return MMI_OK;
 }
 
+extern "C" int mmi_set_wgrad_override(int bm, int bn, int splits) {
+  const bool ok = (bm == 0 && bn == 0) || ((bm == 128 || bm == 64) && (bn == 128 || bn == 64));
+  MMI_CHECK_ARG(ok && splits >= 0, "mmi_set_wgrad_override: (%d,%d,%d): tiles are 128/64 x 128/64 (0,0 = automatic), splits >= 0 (0 = off)", bm, bn, splits);
+  g_wgrad_force[0] = bm; g_wgrad_force[1] = bn; g_wgrad_force[2] = splits;
+  return MMI_OK;
+}
+
 extern "C" int mmi_set_streamk_slots(int slots) {
   const int old = g_sk_slots;
   g_sk_slots = slots;
@@ -1900,6 +1907,7 @@ int wgrad_slots(int bm, int bn, bool vec) {
   return per_cu * device_cus();
 }
 
+int g_wgrad_force[3] = {0, 0, 0};  // bm, bn, splits (0 = automatic)
 WgPlan wgrad_plan(const mmi_conv_desc* d) {
   WgPlan g;
   const int Ntot = d->KH * d->KW * d->Cin;
@@ -1938,6 +1946,16 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
     const int blocks = tiles * sp;
     const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots) - pen * sp;
     if (eff > best + 1e-9) best = eff, splits = sp;
+  }
+  if (g_wgrad_force[2] > 0) {       // mmi_set_wgrad_override (tuning, tools/sweep_wgrad.py): force tile variant and split count
+    if (g.vec && g_wgrad_force[0] > 0) {
+      g.bm = g_wgrad_force[0];
+      g.bn = g_wgrad_force[1];
+      g.mtiles = cdiv(d->Cout, g.bm);
+      g.ntiles = cdiv(Ntot, g.bn);
+    }
+    splits = g_wgrad_force[2];
+    if (splits > (int)((Mpix + BK - 1) / BK)) splits = (int)((Mpix + BK - 1) / BK);
   }
   g.chunk = cdiv(cdiv(Mpix, splits), BK) * BK;
   g.splits = cdiv(Mpix, g.chunk);

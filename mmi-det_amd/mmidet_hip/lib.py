@@ -45,6 +45,7 @@ _SIGS = {
     'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
     'mmi_set_streamk_slots': (c_int, [c_int]),
     'mmi_set_tile_override': (c_int, [c_int, c_int]),
+    'mmi_set_wgrad_override': (c_int, [c_int, c_int, c_int]),
     'mmi_set_gemm_precision': (c_int, [c_int]),
     'mmi_set_uniform_loaders': (c_int, [c_int]),
     'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
@@ -196,5 +197,5 @@ def _bump(fn):
     return wrapped
 
 
-for _name in ('set_streamk_slots', 'set_tile_override', 'set_gemm_precision', 'set_uniform_loaders'):
+for _name in ('set_streamk_slots', 'set_tile_override', 'set_gemm_precision', 'set_uniform_loaders', 'set_wgrad_override'):
     globals()[_name] = _bump(globals()[_name])
