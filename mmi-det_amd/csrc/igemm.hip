@@ -1408,6 +1408,7 @@ struct FwdPlan {
 int g_uniform_loaders = getenv("MMIDET_UNIFORM_LOADERS") ? atoi(getenv("MMIDET_UNIFORM_LOADERS")) : 1;
 int g_gemm_prec = 0;  // mmi_set_gemm_precision: 0 = exact fp32 MFMA, 1 = split-bf16 products for forward-layout GEMMs
 int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
+int g_wgrad_force[3] = {0, 0, 0};  // mmi_set_wgrad_override (tuning): bm, bn, splits (0 = automatic)
 FwdPlan plan_tiles(int64_t M, int Ncol) {
   FwdPlan f;
   if (g_tile_bm > 0) {
@@ -1907,7 +1908,6 @@ int wgrad_slots(int bm, int bn, bool vec) {
   return per_cu * device_cus();
 }
 
-int g_wgrad_force[3] = {0, 0, 0};  // bm, bn, splits (0 = automatic)
 WgPlan wgrad_plan(const mmi_conv_desc* d) {
   WgPlan g;
   const int Ntot = d->KH * d->KW * d->Cin;
