@@ -1947,6 +1947,26 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
     const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots) - pen * sp;
     if (eff > best + 1e-9) best = eff, splits = sp;
   }
+  // Short-K GEMMs (the token projections: 2048 rows, i.e. at most 64 K-steps): tools/sweep_wgrad.py,
+  // profiles/r02_sweep_wgrad.txt.  What wins there is enough workgroups WITHOUT leaving the in-launch fold (<= 4 splits): the
+  // largest tile variant that gives >= 512 tiles unsplit (1024 -> 4096: 64x128, 1.21x over 128x128 x 3 splits), else 64x64
+  // tiles with up to four splits (1024 -> 1024: 1.30x, 512 <-> 2048: 1.33x).
+  if (g.vec && Mpix <= 4096 && cdiv(d->Cout, 64) * cdiv(Ntot, 64) >= 256 && g_wgrad_force[2] == 0) {
+    static const int cand[3][2] = {{128, 128}, {64, 128}, {64, 64}};
+    int pick = 2;
+    for (int c = 0; c < 3; ++c)
+      if ((int64_t)cdiv(d->Cout, cand[c][0]) * cdiv(Ntot, cand[c][1]) >= 512) {
+        pick = c;
+        break;
+      }
+    g.bm = cand[pick][0];
+    g.bn = cand[pick][1];
+    g.mtiles = cdiv(d->Cout, g.bm);
+    g.ntiles = cdiv(Ntot, g.bn);
+    tiles = g.mtiles * g.ntiles;
+    splits = tiles >= 512 ? 1 : min(4, cdiv(1024, tiles));
+    if (splits > max_splits) splits = max_splits < 1 ? 1 : max_splits;
+  }
   if (g_wgrad_force[2] > 0) {       // mmi_set_wgrad_override (tuning, tools/sweep_wgrad.py): force tile variant and split count
     if (g.vec && g_wgrad_force[0] > 0) {
       g.bm = g_wgrad_force[0];
