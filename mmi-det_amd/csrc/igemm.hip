@@ -1967,6 +1967,22 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
     splits = tiles >= 512 ? 1 : min(4, cdiv(1024, tiles));
     if (splits > max_splits) splits = max_splits < 1 ? 1 : max_splits;
   }
+  // 1x1 convolutions over many pixels (the same sweep): the output is a few tiles and everything is split-K; 64x64 tiles put
+  // 512..1024 workgroups on the chip with a third to a tenth of the splits -- i.e. of the slab traffic -- of one or two wide
+  // tiles (128 -> 64 @160x160: 1.45x, 256 -> 128 @80x80: 1.25x, 512 -> 256 @40x40 and 1024 -> 512 @20x20: 1.22x).
+  if (g.vec && d->KH * d->KW == 1 && Mpix > 4096 && g_wgrad_force[2] == 0) {
+    const int t64 = cdiv(d->Cout, 64) * cdiv(Ntot, 64);
+    if (t64 >= 8 || d->Cout <= 64) {
+      g.bm = g.bn = 64;
+      g.mtiles = cdiv(d->Cout, 64);
+      g.ntiles = cdiv(Ntot, 64);
+      tiles = t64;
+      const int by_pixels = (int)((Mpix + 511) / 512);
+      splits = cdiv(t64 >= 8 ? 1024 : 512, t64);
+      if (splits > by_pixels) splits = by_pixels;
+      if (splits < 1) splits = 1;
+    }
+  }
   if (g_wgrad_force[2] > 0) {       // mmi_set_wgrad_override (tuning, tools/sweep_wgrad.py): force tile variant and split count
     if (g.vec && g_wgrad_force[0] > 0) {
       g.bm = g_wgrad_force[0];

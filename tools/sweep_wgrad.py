@@ -19,6 +19,9 @@ SHAPES = [  # (B, H, W, Cin, Cout, k, s), launches per step
     ((2048, 1, 1, 1024, 1024, 1, 1), 32), ((2048, 1, 1, 512, 512, 1, 1), 32), ((2048, 1, 1, 256, 256, 1, 1), 32),
     ((2048, 1, 1, 128, 128, 1, 1), 32), ((2048, 1, 1, 1024, 4096, 1, 1), 8), ((2048, 1, 1, 4096, 1024, 1, 1), 8),
     ((2048, 1, 1, 1024, 3072, 1, 1), 8), ((2048, 1, 1, 512, 2048, 1, 1), 8), ((2048, 1, 1, 2048, 512, 1, 1), 8),
+    ((16, 160, 160, 128, 128, 1, 1), 2), ((16, 80, 80, 256, 256, 1, 1), 3), ((16, 40, 40, 512, 512, 1, 1), 4),
+    ((16, 20, 20, 1024, 1024, 1, 1), 3), ((16, 20, 20, 2048, 1024, 1, 1), 2), ((16, 40, 40, 1024, 256, 1, 1), 2),
+    ((16, 80, 80, 512, 128, 1, 1), 2),
 ]
 TILES = [(128, 128), (128, 64), (64, 128), (64, 64)]
 LADDER = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256]
