@@ -1978,7 +1978,12 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
       g.ntiles = cdiv(Ntot, 64);
       tiles = t64;
       const int by_pixels = (int)((Mpix + 511) / 512);
-      splits = cdiv(t64 >= 8 ? 1024 : 512, t64);
+      if (t64 >= 8) {                    // 512..1024 workgroups, about 800 pixels (25 K-steps) per split where that fits
+        const int lo = cdiv(512, t64), hi = cdiv(1024, t64), want = (int)(Mpix / 800);
+        splits = want < lo ? lo : (want > hi ? hi : want);
+      } else {
+        splits = cdiv(512, t64);
+      }
       if (splits > by_pixels) splits = by_pixels;
       if (splits < 1) splits = 1;
     }
