@@ -1951,7 +1951,8 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   // profiles/r02_sweep_wgrad.txt.  What wins there is enough workgroups WITHOUT leaving the in-launch fold (<= 4 splits): the
   // largest tile variant that gives >= 512 tiles unsplit (1024 -> 4096: 64x128, 1.21x over 128x128 x 3 splits), else 64x64
   // tiles with up to four splits (1024 -> 1024: 1.30x, 512 <-> 2048: 1.33x).
-  if (g.vec && Mpix <= 4096 && cdiv(d->Cout, 64) * cdiv(Ntot, 64) >= 256 && g_wgrad_force[2] == 0) {
+  static const bool sweep_rules = !(getenv("MMIDET_WGRAD_RULES") && atoi(getenv("MMIDET_WGRAD_RULES")) == 0);   // (A/B switch)
+  if (sweep_rules && g.vec && Mpix <= 4096 && cdiv(d->Cout, 64) * cdiv(Ntot, 64) >= 256 && g_wgrad_force[2] == 0) {
     static const int cand[3][2] = {{128, 128}, {64, 128}, {64, 64}};
     int pick = 2;
     for (int c = 0; c < 3; ++c)
@@ -1970,7 +1971,7 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   // 1x1 convolutions over many pixels (the same sweep): the output is a few tiles and everything is split-K; 64x64 tiles put
   // 512..1024 workgroups on the chip with a third to a tenth of the splits -- i.e. of the slab traffic -- of one or two wide
   // tiles (128 -> 64 @160x160: 1.45x, 256 -> 128 @80x80: 1.25x, 512 -> 256 @40x40 and 1024 -> 512 @20x20: 1.22x).
-  if (g.vec && d->KH * d->KW == 1 && Mpix > 4096 && g_wgrad_force[2] == 0) {
+  if (sweep_rules && g.vec && d->KH * d->KW == 1 && Mpix > 4096 && g_wgrad_force[2] == 0) {
     const int t64 = cdiv(d->Cout, 64) * cdiv(Ntot, 64);
     if (t64 >= 8 || d->Cout <= 64) {
       g.bm = g.bn = 64;
