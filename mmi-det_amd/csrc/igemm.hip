@@ -1951,7 +1951,10 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   // profiles/r02_sweep_wgrad.txt.  What wins there is enough workgroups WITHOUT leaving the in-launch fold (<= 4 splits): the
   // largest tile variant that gives >= 512 tiles unsplit (1024 -> 4096: 64x128, 1.21x over 128x128 x 3 splits), else 64x64
   // tiles with up to four splits (1024 -> 1024: 1.30x, 512 <-> 2048: 1.33x).
-  static const bool sweep_rules = !(getenv("MMIDET_WGRAD_RULES") && atoi(getenv("MMIDET_WGRAD_RULES")) == 0);   // (A/B switch)
+  // OFF by default: stand-alone the two rules below take 6 % off the swept shapes (profiles/r02_sweep_wgrad.txt: 30.95 -> 28.0 ms
+  // summed over a step), inside the step -- where every wgrad shares the chip with the lane's dgrad -- they cost 0.6 ms
+  // (profiles/r02_ab_wgrad_rules.txt, three interleaved pairs): more, smaller workgroups interfere more with the co-runner.
+  static const bool sweep_rules = getenv("MMIDET_WGRAD_RULES") && atoi(getenv("MMIDET_WGRAD_RULES")) == 1;   // (A/B switch)
   if (sweep_rules && g.vec && Mpix <= 4096 && cdiv(d->Cout, 64) * cdiv(Ntot, 64) >= 256 && g_wgrad_force[2] == 0) {
     static const int cand[3][2] = {{128, 128}, {64, 128}, {64, 64}};
     int pick = 2;
