@@ -155,6 +155,9 @@ _UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_conv_fwd_row_blocks_bf16', '
 EXPORTS = sorted(_SIGS)
 
 
+_SPIN_US = float(os.environ.get('MMIDET_HOST_SPIN_US', '0'))
+
+
 class MMIError(RuntimeError):
     pass
 
@@ -170,6 +173,16 @@ def _bind(name, restype, argtypes):
         rc = fn(*args)
         if rc != 0:
             raise MMIError('%s failed (%d): %s' % (name, rc, _lib.mmi_last_error().decode()))
+    if _SPIN_US > 0:        # experiment (tools/ab_env.sh MMIDET_HOST_SPIN_US=n): how sensitive is the step to host enqueue time?
+        import time as _time
+
+        def checked(*args):  # noqa: F811
+            rc = fn(*args)
+            if rc != 0:
+                raise MMIError('%s failed (%d): %s' % (name, rc, _lib.mmi_last_error().decode()))
+            t = _time.perf_counter() + _SPIN_US * 1e-6
+            while _time.perf_counter() < t:
+                pass
     checked.__name__ = name
     return checked
 
