@@ -335,7 +335,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ddp = world > 1 or args.ddp
-    comm_kind = os.environ.get('MMIDET_COMM', 'native')     # 'native': mmi_comm_* (RCCL called directly); 'torch': ProcessGroupNCCL
+    # 'torch' (default): torch.distributed / ProcessGroupNCCL = RCCL.  'native': the library's own communicator (mmi_comm_*: RCCL
+    # called directly on the reducer's HIP stream, collectives capturable into the step graph).  Both run the same bucket logic;
+    # interleaved on one box at world size 1 the native transport's step is 3 ms longer (profiles/r02_ab_comm_world1.txt: 125.2 /
+    # 125.9 vs 122.4 / 122.5 ms, also with the collective itself switched off, so it is the process set-up, not the call) and it
+    # has never run at N > 1, so the transport every N > 1 launch takes by default is the measured-faster, mainstream one.
+    comm_kind = os.environ.get('MMIDET_COMM', 'torch')
     if ddp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
