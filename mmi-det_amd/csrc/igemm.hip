@@ -874,6 +874,9 @@ struct WgradP {
 #define MMI_WGRAD_OCC 3
 #endif
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
+#ifndef MMI_WGRAD_LDS_B32
+#define MMI_WGRAD_LDS_B32 1
+#endif
 
 // TAB (pixel-table loaders, the wgrad counterpart of the uniform-tap loaders above).  Here K runs over output pixels, so
 // what every thread of a row has in common is the pixel: per slab ONE wave (taking turns) writes a 32-entry LDS table
@@ -1222,6 +1225,22 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       for (int i = 0; i < ITB; ++i)
         if (MMI_LOAD_SPREAD(ITA + i, g)) load_b_row(i);
       float a[4][TM], b[4][TN];
+#if MMI_WGRAD_LDS_B32
+      // One ds_read_b32 per fragment, each with its own 16-bit immediate offset from ONE per-thread base: left to itself the
+      // compiler pairs the fragments into ds_read2_b32, whose 8-bit offsets do not reach from one k-step to the next (1 KB), and
+      // pays a v_add_u32 per pair -- 28 VALU instructions per K slab next to the MFMA stream (tools/mfma_mix.hip: LDS reads
+      // cost the matrix pipe nothing, VALU instructions do).  `volatile` is what keeps the reads apart.
+      typedef __attribute__((address_space(3))) const volatile float* lds_vfp;   // (stays an LDS access: ds_read_b32)
+      lds_vfp ap = (lds_vfp)(As + lh * BM + wm * WM + l31);
+      lds_vfp bp = (lds_vfp)(Bs + lh * BN + wn * WN + l31);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[e][i] = ap[2 * (4 * g + e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[e][j] = bp[2 * (4 * g + e) * BN + j * 32];
+      }
+#else
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -1229,6 +1248,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[e][j] = Bs[(2 * (4 * g + e) + lh) * BN + wn * WN + j * 32 + l31];
       }
+#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
