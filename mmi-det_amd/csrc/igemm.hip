@@ -874,8 +874,12 @@ struct WgradP {
 #define MMI_WGRAD_OCC 3
 #endif
 #define MMI_WGRAD_STAGES ((BM == 64 && BN == 64) ? 2 : 1)
+// MMI_WGRAD_LDS_B32 = 1: one ds_read_b32 with a 16-bit immediate per MFMA fragment instead of the compiler's ds_read2_b32 pairs +
+// a v_add_u32 per pair: 29 -> 5 VALU instructions per K slab, +2..8 % stand-alone on every shape (3x3 128->128: 112.1 -> 114.1
+// TFLOP/s) -- and 1.0 ms SLOWER inside the step (122.75 vs 121.7 ms, three interleaved pairs, profiles/r02_ab_wgrad_lds_b32.txt):
+// twice the LDS instructions, and in the step wgrad shares every CU's LDS pipe with the lane's dgrad.  The step decides: off.
 #ifndef MMI_WGRAD_LDS_B32
-#define MMI_WGRAD_LDS_B32 1
+#define MMI_WGRAD_LDS_B32 0
 #endif
 
 // TAB (pixel-table loaders, the wgrad counterpart of the uniform-tap loaders above).  Here K runs over output pixels, so
