@@ -50,6 +50,8 @@ class _Staging:
 
 
 class FusedSGDEMA:
+    TAIL_PREFIX = 'Enhance.'     # state_dict prefix of the modules whose backward runs last (models/yolo_test.py: self.Enhance)
+
     def __init__(self, model, groups, ema_model=None, ema_decay=0.9999, ema_updates=0):
         """groups: list of dicts {'params': [...], 'lr':, 'momentum':, 'weight_decay':} (at most 3)."""
         assert 1 <= len(groups) <= 3
@@ -105,21 +107,40 @@ class FusedSGDEMA:
         ck = np.array(chunks, dtype=np.int32).reshape(-1, 2)
         self._nchunks = len(chunks)
         self._chunks_dev = torch.from_numpy(ck).to(self.device)
+        # Two-part launch (TrainStep's early optimizer): "tail" = the records of the modules whose gradients arrive last in
+        # backward (the Contour Enhancement Module in front of the RGB stem); everything else can be stepped while the tail's
+        # backward is still running.  Same table, two chunk lists.
+        tail_ptrs = {v.data_ptr() for k, v in msd.items() if k.startswith(self.TAIL_PREFIX)}
+        self._tail_rows = np.array([r[0] in tail_ptrs for r in rows], dtype=bool)
+        self._sgd_tail = [p.data_ptr() in tail_ptrs for p in self._sgd_params]
+        self._part_chunks = {}
+        for name, want in (('head', False), ('tail', True)):
+            sel = [c for c in chunks if bool(self._tail_rows[c[0]]) == want]
+            arr = np.array(sel, dtype=np.int32).reshape(-1, 2)
+            self._part_chunks[name] = (torch.from_numpy(arr).to(self.device) if len(sel) else None, len(sel))
         nbytes = rec.view(np.uint8).reshape(-1).size
         self._recs_stage = _Staging(nbytes, self.device)
         self._recs_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
-    def _refresh_grads(self):
+    def _refresh_grads(self, part=None):
         """Gradients are fresh tensors every eager step (AccumulateGrad steals them); re-point the table when they move.
-        Under graph capture/replay the addresses are static and this is a no-op after the capture pass."""
+        Under graph capture/replay the addresses are static and this is a no-op after the capture pass.
+        part='head': only the non-tail parameters must have their gradient yet (the tail's backward is still to run; its rows
+        keep last step's pointers, which the head launch never reads).  Returns False if a needed gradient is missing."""
         ptrs = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self._sgd_params)
+        if part == 'head':
+            if any(gp == 0 and not tl for gp, tl in zip(ptrs, self._sgd_tail)):
+                return False
+            old = self._gptrs or (0,) * len(ptrs)
+            ptrs = tuple(gp if not tl else og for gp, tl, og in zip(ptrs, self._sgd_tail, old))
         if ptrs == self._gptrs:
-            return
+            return True
         self._gptrs = ptrs
         rec = self._recs_host
         n = len(ptrs)
-        aligned = 0
         for i, (p, gp) in enumerate(zip(self._sgd_params, ptrs)):
+            if part == 'head' and self._sgd_tail[i]:
+                continue
             if gp == 0:
                 raise RuntimeError('parameter without gradient in an optimiser group (all are trained in the reference)')
             assert p.grad.stride() == p.stride(), 'gradient layout differs from the parameter layout'
@@ -127,6 +148,7 @@ class FusedSGDEMA:
         al = ((rec['p'] | rec['g'] | rec['buf'] | rec['ema']) & np.uint64(15)) == 0
         rec['flags'] = (rec['flags'] & ~np.int32(4)) | np.where(al, 4, 0).astype(np.int32)
         self._recs_stage.upload(torch.from_numpy(rec.view(np.uint8).reshape(-1)), self._recs_dev)
+        return True
 
     # ---- per step ----------------------------------------------------------------------------------------------------
     def upload_hyper(self, advance=True):
@@ -146,6 +168,17 @@ class FusedSGDEMA:
         self._refresh_grads()
         lib.sgd_ema_step(self._recs_dev.data_ptr(), self._chunks_dev.data_ptr(), self._nchunks, self._hyper_dev.data_ptr(),
                          _stream())
+
+    def launch_part(self, part, stream=None):
+        """'head' (everything but the tail records) or 'tail'; head's table refresh happens on the CURRENT stream -- the caller
+        orders `stream` behind it.  Returns False (nothing launched) when a head gradient is not there yet."""
+        if not self._refresh_grads('head' if part == 'head' else None):
+            return False
+        ck, n = self._part_chunks[part]
+        if n:
+            lib.sgd_ema_step(self._recs_dev.data_ptr(), ck.data_ptr(), n, self._hyper_dev.data_ptr(),
+                             _stream() if stream is None else stream)
+        return True
 
     def step(self):
         self.upload_hyper()

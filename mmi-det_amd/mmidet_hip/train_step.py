@@ -14,6 +14,8 @@ dropout masks come from a device seed word, and nothing in the step synchronises
 microseconds per step instead of ~175 ms enqueueing launches.  Graph mode needs a fixed batch shape and target count
 (pad the target list with rows whose image index is negative: the assignment kernel skips them).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -94,6 +96,13 @@ class TrainStep:
         self._graph_has_collectives = False
         assert not (graph and self.accumulate != 1), 'graph mode captures one full step: accumulate must be 1'
         assert not (graph and not fused_optimizer), 'graph mode needs the fused optimizer (device-resident hyper-parameters)'
+        # Early optimizer (eager, one GPU): the step ends on a lone stream -- the Contour Enhancement Module's backward (3 ms
+        # at 640x640) and then the optimizer (1 ms).  Every other gradient is complete when the gradient of the CEM's OUTPUT
+        # arrives, so a tensor hook there launches the optimizer for everything but the CEM's own parameters on a stream of
+        # its own, next to the CEM backward; the CEM's records follow after backward (FusedSGDEMA.launch_part).
+        self.early_opt = os.environ.get('MMIDET_EARLY_OPT', '1') != '0'
+        self._opt_stream = None
+        self._head_launched = False
 
     # ---- the step body (eager; also what gets captured) ----------------------------------------------------------------
     def _body(self, imgs_u8, targets, reduce=True):
@@ -111,7 +120,13 @@ class TrainStep:
         else:
             imgs = imgs_u8.float() / 255.0                                              # train.py:743
             rgb, ir = imgs[:, :3], imgs[:, 3:]                                          # train.py:744-745 (strided views)
-        pred, comb = model(rgb, ir)                                                     # train.py:788
+        early = (self.early_opt and defer and self.fused and self.reducer is None and self.accumulate == 1 and imgs_u8.is_cuda
+                 and not torch.cuda.is_current_stream_capturing() and getattr(model, 'two_streams', False))
+        model._tail_hook = self._on_tail_gradient if early else None                    # registered on the CEM's output in forward
+        try:
+            pred, comb = model(rgb, ir)                                                 # train.py:788
+        finally:
+            model._tail_hook = None
         loss, items = self.compute_loss(pred, targets, comb.reshape(-1))                # train.py:789 (+ B2 reshape)
         if self.world_size > 1:
             loss = loss * self.world_size                                               # train.py:790-791
@@ -126,6 +141,7 @@ class TrainStep:
                 raise RuntimeError('TrainStep: %s.grad is set at the start of backward (zero_grad(set_to_none=True) was skipped); '
                                    'the deferred-join wgrad overlap needs .grad to be None' % stale)
         ops.DEFER_JOIN = defer
+        self._head_launched = False
         try:
             loss.sum().backward()                                                       # train.py:796
         finally:
@@ -134,6 +150,29 @@ class TrainStep:
         if reduce:
             self.reducer.finish()                                                       # mean over ranks, as DDP
         return loss, items
+
+    def _on_tail_gradient(self, grad):
+        """Tensor hook on the CEM's output (runs in backward right before the CEM's own backward node, on the RGB lane's
+        stream): every gradient except the CEM's has been enqueued -- on this stream, on the IR lane's, or on a wgrad stream."""
+        if self._head_launched:
+            return None
+        opt, dev = self.optimizer, grad.device
+        cur = torch.cuda.current_stream()
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=dev)
+        side = self._opt_stream
+        opt.upload_hyper()                                   # (current stream; the tail launch reuses the block)
+        if not opt._refresh_grads('head'):
+            opt.updates -= 1                                 # some gradient is not there yet: leave everything to _update
+            opt._steps -= 1
+            return None
+        side.wait_stream(cur)                                # table + hyper-parameter uploads, lane gradients, BN vectors
+        side.wait_stream(self.model._ir_stream(dev))
+        for sd in ops.side_streams_in_flight():
+            side.wait_stream(sd)
+        opt.launch_part('head', side.cuda_stream)
+        self._head_launched = True
+        return None
 
     def _named_params(self):
         if getattr(self, '_np_cache', None) is None:
@@ -145,6 +184,10 @@ class TrainStep:
         if self.fused:
             if in_capture:
                 self.optimizer.launch()          # hyper-parameters are uploaded outside the graph, before each replay
+            elif self._head_launched:            # the early optimizer has stepped everything but the tail during backward
+                self.optimizer.launch_part('tail')
+                torch.cuda.current_stream().wait_stream(self._opt_stream)
+                self._head_launched = False
             else:
                 self.optimizer.step()
         else:

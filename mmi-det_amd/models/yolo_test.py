@@ -218,6 +218,9 @@ class Model(nn.Module):
                 x2.record_stream(ir)
             done = {}
         x = self.Enhance(x)                                        # CEM on the RGB stream only
+        hook = getattr(self, '_tail_hook', None)
+        if hook is not None and x.requires_grad:                   # (TrainStep's early optimizer: see _on_tail_gradient)
+            x.register_hook(hook)
         bf16 = getattr(self, 'storage', 'f32') == 'bf16'
         fan = self._fan_skip if torch.is_grad_enabled() else {}
         y = []

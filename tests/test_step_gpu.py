@@ -363,3 +363,30 @@ def test_training_overfits_one_batch():
     assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point)
     assert all(torch.isfinite(v).all() for v in ts.ema.ema.state_dict().values() if v.dtype.is_floating_point)
     assert losses[-1] < 0.8 * losses[0] and all(b < a for a, b in zip(losses, losses[1:])), losses
+
+
+def test_early_optimizer_is_the_same_training():
+    """TrainStep's early optimizer (the SGD+EMA launch for everything but the CEM's records goes on a stream of its own from a
+    tensor hook inside backward, next to the CEM's backward; the CEM's records follow): the same kernels on the same numbers in
+    another launch order -- parameters, momentum-driven trajectories and the EMA copy are bit-identical to the one-launch
+    optimizer after several steps, and the hook really fired."""
+    m1, ts1, cfg = make()
+    m2, ts2, _ = make()
+    ts1.early_opt, ts2.early_opt = True, False
+    fired = []
+    orig = ts1._on_tail_gradient
+    ts1._on_tail_gradient = lambda g: (fired.append(1), orig(g))[1]
+    for i in range(4):
+        b = batch(cfg, 60 + i)
+        l1, _ = ts1.step(*b)
+        l2, _ = ts2.step(*b)
+        assert torch.equal(l1, l2), i
+    assert len(fired) == 4 and ts1._opt_stream is not None
+    torch.cuda.synchronize()
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    e1, e2 = ts1.ema.ema.state_dict(), ts2.ema.ema.state_dict()
+    for k in e1:
+        assert torch.equal(e1[k], e2[k]), 'ema ' + k
+    assert ts1.optimizer.updates == ts2.optimizer.updates == 4
