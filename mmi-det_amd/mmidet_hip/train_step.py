@@ -100,7 +100,9 @@ class TrainStep:
         # at 640x640) and then the optimizer (1 ms).  Every other gradient is complete when the gradient of the CEM's OUTPUT
         # arrives, so a tensor hook there launches the optimizer for everything but the CEM's own parameters on a stream of
         # its own, next to the CEM backward; the CEM's records follow after backward (FusedSGDEMA.launch_part).
-        self.early_opt = os.environ.get('MMIDET_EARLY_OPT', '1') != '0'
+        # Measured (profiles/r02_ab_early_optimizer.txt, three interleaved pairs): 121.47 vs 121.65 ms -- both sides of the overlap
+        # stream HBM, so it buys 0.2 ms; bit-identical training (tests/test_step_gpu.py).  Off unless MMIDET_EARLY_OPT=1.
+        self.early_opt = os.environ.get('MMIDET_EARLY_OPT', '0') == '1'
         self._opt_stream = None
         self._head_launched = False
 
