@@ -667,6 +667,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
 #pragma unroll
         for (int i = 0; i < NB; ++i)
           if (MMI_LOAD_SPREAD(RA + i, g)) load_b_row(i);
+        // a wave whose 32-column blocks all lie beyond the last output column (Focus' input gradient: N = 12 in a 64-wide
+        // tile) has nothing to multiply: it still loads and synchronises, but leaves the matrix pipe to the others
+        if constexpr (DGRAD && BN == 64 && !SK) {      // (only where it occurs: elsewhere the branch costs registers)
+          if (n0 + wn * WN >= p.Ncol) continue;
+        }
         f32x4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
