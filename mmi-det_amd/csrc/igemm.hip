@@ -276,8 +276,12 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 #ifndef MMI_UNI_OCC
 #define MMI_UNI_OCC 3
 #endif
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false>
+// W41 (narrow outputs: Focus' input gradient has N = 12): the four waves are stacked along M, each owning 32 rows x the whole
+// tile width, and skip the 32-column blocks beyond the last output column -- in the 2 x 2 layout half of the waves would own
+// nothing but padding and leave their SIMDs' matrix pipes idle.
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
+  static_assert(!W41 || (DGRAD && !SK && PREC == 0 && !EPI && BM == 128), "the stacked wave layout exists for the plain fp32 dgrad tiles");
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
   // PREC = 4 (bf16 STORAGE): the activation operand A and the output C live in HBM as bf16 (the weights stay
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   // floats per [row][k] LDS record: fp32 32 + 4 pad; split forms NP x 64 B of bf16 + 16 B pad (20, 36 or 52 floats: each makes
   // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
   constexpr int RSF = ONE ? 20 : (PREC >= 2 ? 52 : LDS_PAD);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int WM = W41 ? BM / 4 : BM / 2, WN = W41 ? BN : BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int RA = BM / RPP;                      // A rows per loader thread
   constexpr int A_ELEMS = BM * RSF;
   // split-bf16 dgrad: the weight tile stays k-major ([k][n], as it comes from OHWI memory) in two bf16 planes whose rows are
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   __shared__ int bn_flag;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = W41 ? wave : wave >> 1, wn = W41 ? 0 : wave & 1;
   Taps tp{0, 1, 0, 1, p.KW, p.Ktot};
   int pa = 0, qa = 0, Pc = p.P, Qc = p.Q, Mc = p.M, ntile_tot = p.mtiles * p.ntiles;
   if (!SK && DGRAD && p.par) {  // uniform per workgroup
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           if (MMI_LOAD_SPREAD(RA + i, g)) load_b_row(i);
         // a wave whose 32-column blocks all lie beyond the last output column (Focus' input gradient: N = 12 in a 64-wide
         // tile) has nothing to multiply: it still loads and synchronises, but leaves the matrix pipe to the others
-        if constexpr (DGRAD && BN == 64 && !SK) {      // (only where it occurs: elsewhere the branch costs registers)
+        if constexpr (DGRAD && BN == 64 && !SK && !W41) {      // (only where it occurs: elsewhere the branch costs registers)
           if (n0 + wn * WN >= p.Ncol) continue;
         }
         f32x4 a[TM], b[TN];
@@ -691,8 +695,12 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (W41) {
+                if (j > 0 && n0 + j * 32 >= p.Ncol) continue;      // (uniform: a column block of pure padding)
+              }
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
       }
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
@@ -1654,6 +1662,14 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     else LAUNCH(64, 64, false);
   } else if (uni) {
 #define LAUNCH_UNI(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 0, EPI, true>), grid, block, 0, s, p)
+    if constexpr (DGRAD && !EPI) {
+      static const bool w41_off = getenv("MMIDET_DGRAD_W41") != nullptr && atoi(getenv("MMIDET_DGRAD_W41")) == 0;   // (A/B switch)
+      if (f.bm == 128 && f.bn == 64 && p.Ncol <= 32 && !w41_off) {
+        hipLaunchKernelGGL((igemm_kernel<128, 64, true, true, false, 0, false, true, true>), grid, block, 0, s, p);
+        MMI_CHECK_LAUNCH(who);
+        return MMI_OK;
+      }
+    }
     if (f.bm == 128 && f.bn == 128) LAUNCH_UNI(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_UNI(128, 64);
     else LAUNCH_UNI(64, 64);

@@ -64,6 +64,8 @@ CONV_CASES = [
     (2, 10, 10, 256, 33, 1, 1),    # Detect head: Cout=33
     (4, 40, 40, 128, 128, 3, 1),   # 128x128 tile path (M=6400)
     (2, 64, 64, 64, 64, 1, 1),
+    (4, 128, 128, 12, 64, 3, 1),   # Focus at a size that takes the 128x64 dgrad tile with N = 12: stacked wave layout (W41)
+    (4, 128, 130, 20, 32, 3, 1),   # the same with N = 20 and ragged rows
 ]
 
 
