@@ -32,6 +32,38 @@ def build_pair(kind, size):
     return m.to(dev()), o, cfg
 
 
+_L640 = {}
+
+
+def oracle_l640_fp32():
+    """The CPU oracle's yolov5l two-stream-fourier training step at 640x640, batch 2, hash weights, dropout 0, seed 3, in fp32:
+    evaluated ONCE per test session (15 s of host time) and shared by the full-size tests below."""
+    if not _L640:
+        import yaml
+        from oracle import portable_init
+        from oracle.ref_loss import ComputeLoss as OLoss, scaled_hyp
+        from oracle.ref_model import Model as OModel
+        here = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(here, '..', 'mmi-det_amd', 'models', 'transformer',
+                               'yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml')) as f:
+            cfg = yaml.safe_load(f)
+        cfg['nc'] = 6
+        o = OModel(cfg, dropout=0.0)
+        sd = portable_init.fill_(o.state_dict())
+        o.load_state_dict(sd)
+        o.nc, o.gr, o.hyp = 6, 1.0, scaled_hyp(6, 640)
+        o.train()
+        imgs, targets = portable_init.synth_batch(2, 640, 6, per_image=8, seed=3)
+        x = imgs.float() / 255
+        po, co = o(x[:, :3], x[:, 3:])
+        lo, io = OLoss(o)(po, targets, co.reshape(-1))
+        lo.backward()
+        _L640.update(cfg=cfg, sd={k: v.clone() for k, v in sd.items()}, x=x, targets=targets, preds=[t.detach() for t in po],
+                     comb=co.detach(), loss=lo.detach(), items=io.detach(),
+                     grads={n: p.grad for n, p in o.named_parameters() if p.grad is not None})
+    return _L640
+
+
 @pytest.mark.parametrize('kind', ['add', 'fourier'])
 def test_train_step_matches_reference_fixture_and_oracle(kind):
     from oracle import portable_init
@@ -195,35 +227,20 @@ def test_yolov5l_640_train_step_matches_oracle(gemm):
     ulp of the tie) falls the other way, which moves every gradient upstream of it by ~1e-2.  Which arithmetic that happens to
     depends on the seed: of four seeds it hit the fp32 path once (median 3e-3, worst 1.1e-2) and the split forms once
     (4e-3, 2.3e-2) (profiles/r01_gemm_modes_full_size_gradients.txt).  So the bound is the event level, not the rounding level."""
-    import yaml
     from models.yolo_test import Model
-    from oracle import portable_init
-    from oracle.ref_loss import ComputeLoss as OLoss, scaled_hyp
-    from oracle.ref_model import Model as OModel
+    from oracle.ref_loss import scaled_hyp
     from utils.loss import ComputeLoss
     from mmidet_hip import lib
-    here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, '..', 'mmi-det_amd', 'models', 'transformer',
-                           'yolov5l_fusion_transformer_M3FD_fuse3_fourier.yaml')) as f:
-        cfg = yaml.safe_load(f)
-    cfg['nc'] = 6
-    o = OModel(cfg, dropout=0.0)
-    sd = portable_init.fill_(o.state_dict())
-    o.load_state_dict(sd)
+    ref = oracle_l640_fp32()
+    cfg, x, targets = ref['cfg'], ref['x'], ref['targets']
+    po, co, lo, io = ref['preds'], ref['comb'], ref['loss'], ref['items']
     m = Model(cfg)
-    m.load_state_dict(sd, strict=True)
+    m.load_state_dict(ref['sd'], strict=True)
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    for mm in (o, m):
-        mm.nc, mm.gr, mm.hyp = 6, 1.0, scaled_hyp(6, 640)
+    m.nc, m.gr, m.hyp = 6, 1.0, scaled_hyp(6, 640)
     m = m.to(dev()).train()
-    o.train()
-    imgs, targets = portable_init.synth_batch(2, 640, 6, per_image=8, seed=3)
-    x = imgs.float() / 255
-    po, co = o(x[:, :3], x[:, 3:])
-    lo, io = OLoss(o)(po, targets, co.reshape(-1))
-    lo.backward()
     xd = x.to(dev())
     lib.set_gemm_precision(gemm)
     try:
@@ -238,7 +255,7 @@ def test_yolov5l_640_train_step_matches_oracle(gemm):
     close(lg, lo, what='loss', tol=1e-4)
     close(ig, io, what='loss items', tol=1e-4)
     close(cg, co, what='Combine_loss', tol=1e-4)
-    og = dict(o.named_parameters())
+    og = ref['grads']
     checked = 0
     errs = []
     for n, p in m.named_parameters():
@@ -247,7 +264,7 @@ def test_yolov5l_640_train_step_matches_oracle(gemm):
                                     'model.13.trans_blocks.0.sa.que_proj.weight', 'model.6.conv2.weight', 'Enhance.conv3',
                                     'model.49.m.1', 'model.38.m.0.cv2.bn')):
             continue
-        r = og[n].grad
+        r = og.get(n)
         if r is None or float(r.norm()) < 1e-9:
             continue
         errs.append((rel_err(p.grad, r), n))
@@ -315,7 +332,8 @@ def test_yolov5l_640_gradients_against_the_fp64_arbiter():
         for k in range(len(pr)):
             got = float((g * portable_init.signs(g.numel(), '%s#%d' % (n, k))).sum())
             assert abs(got - pr[k]) <= 1e-7 * nrm + 1e-300, (n, k, got, pr[k])
-    g32, l32, p32 = run_oracle(torch.float32)
+    ref32 = oracle_l640_fp32()                      # (the same inputs and weights: synth_batch seed 3, hash weights)
+    g32, l32, p32 = ref32['grads'], ref32['loss'], ref32['preds']
     m = Model(cfg)
     m.load_state_dict(portable_init.fill_(m.state_dict()), strict=True)
     for mod in m.modules():
