@@ -375,6 +375,12 @@ int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float
  * y3's statistics partials [mmi_cem_blocks][2][3] come out of the fused kernel, the output of the module is then
  * mmi_bn_act_fwd(y3, ..., residual = x).  y2, t (24 channels) and the channel-sum map are written for the backward when
  * non-NULL (training); inference passes NULL and moves 1 read of x + 1 write of y3.  w2 = [24][9][3], w3 = [3][9][24] (OHWI). */
+/* Middle of the CEM backward in one kernel: dy3 (N,H,W,3; gradient of conv3's output) -> dt = conv3^T(dy3) -> stencil-bank backward ->
+ * dr (N,H,W,24; gradient of r), dfactor[24], dbias[24] (EnhanceConv2d's parameters), with dt and the eight D maps in LDS.
+ * Replaces mmi_conv_dgrad(conv3) + mmi_sobel_add_bwd.  w3 = [3][9][24] (OHWI), chansum = the forward's channel-sum map. */
+size_t mmi_cem_bwd_mid_workspace(int N, int H, int W);
+int mmi_cem_bwd_mid(const float* dy3, const float* w3, const float* chansum, const float* factor, float* dr, float* dfactor,
+                    float* dbias, void* workspace, int N, int H, int W, void* stream);
 int mmi_cem_blocks(int N, int H, int W);
 int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_partials, int N, int H, int W, void* stream);
 int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const float* mean_invstd2, const float* gamma2, const float* beta2,

@@ -547,6 +547,154 @@ __global__ void sobel_bwd2_kernel(const float* __restrict__ dt, int ldd, const f
   }
 }
 
+// ---- fused middle of the CEM backward (round 2): dy3 -> dt = conv3^T(dy3) -> stencil-bank backward -> dr, one 16x16 tile at
+// a time with dt (18x18x24) and the eight D maps (18x18x8) in LDS: replaces the transposed smallconv_kernel (writes dt),
+// sobel_bwd1 (reads dt, writes D) and sobel_bwd2 (reads dt and D, writes dr) -- 1.26 GB of dt and 0.42 GB of D never touch HBM.
+// dt is computed with packed fp32 FMAs, two positions per thread (as the forward's conv2), the weights of OB output channels
+// per scalar fetch.  The workgroups walk the tiles grid-stride and keep their dbias / dfactor partial sums in registers, so the
+// 48 wave reductions happen once per workgroup (partials[block][2][24] -> mmi_pair_colsum, as sobel_bwd1).
+// dt is zero outside the image (those positions hold no stencil output in the forward), dy3 likewise (zero padding).
+template <int OB>
+__global__ __launch_bounds__(256) void cem_bwd_mid_kernel(const float* __restrict__ dy3, const float* __restrict__ w3,
+                                                          const float* __restrict__ R, const float* __restrict__ factor,
+                                                          float* __restrict__ dr, float* __restrict__ partials, int N, int H, int W) {
+  constexpr int YS = TS + 4, DT = TS + 2;          // 20, 18
+  __shared__ float dys[YS * YS * 3];
+  __shared__ __align__(16) float dts[DT * DT * 24];
+  __shared__ __align__(16) float Ds[DT * DT * 8];
+  __shared__ float Rs[DT * DT];
+  __shared__ float red[2][4][24];
+  const int t = threadIdx.x;
+  const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS, ntiles = tw * th * N;
+  float db[24], df[24];
+#pragma unroll
+  for (int c = 0; c < 24; ++c) db[c] = df[c] = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tw * th), rr = tile - n * tw * th;
+    const int h0 = (rr / tw) * TS, w0 = (rr % tw) * TS;
+    __syncthreads();
+    for (int e = t; e < YS * YS * 3; e += 256) {
+      const int c = e % 3, q = e / 3, ih = h0 - 2 + q / YS, iw = w0 - 2 + q % YS;
+      dys[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? dy3[(((int64_t)n * H + ih) * W + iw) * 3 + c] : 0.f;
+    }
+    for (int q = t; q < DT * DT; q += 256) {
+      const int ih = h0 - 1 + q / DT, iw = w0 - 1 + q % DT;
+      Rs[q] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? R[((int64_t)n * H + ih) * W + iw] : 0.f;
+    }
+    __syncthreads();
+    // ---- dt on the 18x18 region, two positions (q, q + 162) per thread
+    if (t < DT * DT / 2) {
+      int qq[2];
+      bool in[2];
+      f32x2 xin[27];
+      {
+        const float* sp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          qq[h] = t + h * (DT * DT / 2);
+          const int i = qq[h] / DT, j = qq[h] % DT, ih = h0 - 1 + i, iw = w0 - 1 + j;
+          in[h] = ih >= 0 && iw >= 0 && ih < H && iw < W;
+          sp[h] = dys + ((i + 2) * YS + j + 2) * 3;          // the position itself in dys; tap (ky, kx) reads (i + 2 - ky, j + 2 - kx)
+        }
+#pragma unroll
+        for (int tt = 0; tt < 9; ++tt) {                     // e = tt * 3 + o with tap = 8 - tt: the order of the transposed smallconv_kernel
+          const int ky = (8 - tt) / 3, kx = (8 - tt) % 3;
+#pragma unroll
+          for (int o = 0; o < 3; ++o) {
+            const int off = -(ky * YS + kx) * 3 + o;
+            xin[tt * 3 + o] = f32x2{sp[0][off], sp[1][off]};
+          }
+        }
+      }
+#pragma unroll 1
+      for (int c0 = 0; c0 < 24; c0 += OB) {
+        f32x2 acc[OB];
+#pragma unroll
+        for (int k = 0; k < OB; ++k) acc[k] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 9; ++tt)
+#pragma unroll
+          for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int k = 0; k < OB; ++k) {
+              const float w = w3[(o * 9 + (8 - tt)) * 24 + c0 + k];
+              acc[k] += xin[tt * 3 + o] * f32x2{w, w};
+            }
+#pragma unroll
+        for (int k = 0; k < OB; ++k) {
+          dts[qq[0] * 24 + c0 + k] = in[0] ? acc[k][0] : 0.f;
+          dts[qq[1] * 24 + c0 + k] = in[1] ? acc[k][1] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D_k = sum_{o % 8 == k} factor[o] * dt_o on the 18x18 region
+    for (int q = t; q < DT * DT; q += 256) {
+      float dk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dk[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 24; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dts + q * 24 + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dk[(c + k) & 7] += factor[c + k] * v[k];
+      }
+      *reinterpret_cast<f32x4*>(Ds + q * 8) = f32x4{dk[0], dk[1], dk[2], dk[3]};
+      *reinterpret_cast<f32x4*>(Ds + q * 8 + 4) = f32x4{dk[4], dk[5], dk[6], dk[7]};
+    }
+    __syncthreads();
+    // ---- the tile's own 16x16 positions: dr = dt + sum_k stencil_k^T(D_k); dbias / dfactor sums
+    const int ti = t >> 4, tj = t & 15, oh = h0 + ti, ow = w0 + tj;
+    if (oh < H && ow < W) {
+      const int q = (ti + 1) * DT + tj + 1;
+      float dn[8][9], nb[9], st[8];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const int qn = q + (d / 3 - 1) * DT + d % 3 - 1;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ds + qn * 8), b = *reinterpret_cast<const f32x4*>(Ds + qn * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dn[k][d] = a[k];
+          dn[4 + k][d] = b[k];
+        }
+        nb[d] = Rs[qn];
+      }
+      const float add = stencils8_t(dn);
+      stencils8(nb, st);
+      float* dst = dr + (((int64_t)n * H + oh) * W + ow) * 24;
+#pragma unroll
+      for (int c = 0; c < 24; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dts + q * 24 + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          db[c + k] += v[k];
+          df[c + k] += v[k] * st[(c + k) & 7];
+        }
+        *reinterpret_cast<f32x4*>(dst + c) = f32x4{v[0] + add, v[1] + add, v[2] + add, v[3] + add};
+      }
+    }
+  }
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int c = 0; c < 24; ++c) {
+    float a = db[c], b = df[c];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+      a += __shfl_xor(a, k);
+      b += __shfl_xor(b, k);
+    }
+    if (lane == 0) {
+      red[0][wv][c] = a;
+      red[1][wv][c] = b;
+    }
+  }
+  __syncthreads();
+  if (t < 48) {
+    const int sidx = t / 24, c = t - sidx * 24;
+    partials[((int64_t)blockIdx.x * 2 + sidx) * 24 + c] = red[sidx][0][c] + red[sidx][1][c] + red[sidx][2][c] + red[sidx][3][c];
+  }
+}
+
 }  // namespace
 
 // ---- dispatch helpers used by igemm.hip's public conv entry points ------------------------------------------------------
@@ -670,3 +818,22 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
   return MMI_OK;
 }
 
+// ---- fused middle of the CEM backward: host side -----------------------------------------------------------------------
+constexpr int CEM_MID_BLOCKS = 1024;
+extern "C" size_t mmi_cem_bwd_mid_workspace(int N, int H, int W) {
+  const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
+  return (size_t)(tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS) * 2 * 24 * sizeof(float);
+}
+
+extern "C" int mmi_cem_bwd_mid(const float* dy3, const float* w3, const float* chansum, const float* factor, float* dr, float* dfactor,
+                               float* dbias, void* workspace, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(dy3 && w3 && chansum && factor && dr && dfactor && dbias && workspace && N > 0 && H > 0 && W > 0,
+                "mmi_cem_bwd_mid: bad arguments");
+  MMI_CHECK_ARG(((uintptr_t)dr & 15) == 0, "mmi_cem_bwd_mid: dr must be 16-byte aligned");
+  const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
+  const int blocks = tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS;
+  hipLaunchKernelGGL(cem_bwd_mid_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy3, w3, chansum, factor, dr,
+                     (float*)workspace, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_cem_bwd_mid");
+  return mmi_pair_colsum((float*)workspace, blocks, 24, dbias, dfactor, stream);  // (slot 0 -> dbias, slot 1 -> dfactor; consumes the partials)
+}

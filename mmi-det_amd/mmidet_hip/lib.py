@@ -132,6 +132,8 @@ _SIGS = {
     'mmi_upsample2x_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample2x_bwd_bf16': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_cem_blocks': (c_int, [c_int, c_int, c_int]),
+    'mmi_cem_bwd_mid_workspace': (c_size_t, [c_int, c_int, c_int]),
+    'mmi_cem_bwd_mid': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'mmi_cem_conv2_stats': (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
     'mmi_cem_fused_fwd': (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'mmi_comm_available': (c_int, []),

@@ -959,6 +959,7 @@ def sobel_add(r, factor, bias):
 
 
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
+CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
 
 
 class _CemFused(Function):
@@ -1019,16 +1020,22 @@ class _CemFused(Function):
         # conv3: t (24) -> y3 (3)
         d3 = ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3)
         dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
-        dt = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
-        conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
-        # stencil bank
-        dr = torch.empty_like(dt)
+        dr = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
         df = torch.empty(24, dtype=torch.float32, device=dev)
         dsb = grad_like(sbias)
-        nbytes = lib.sobel_add_bwd_workspace(n, h, w, 24)
-        ws = scratch(nbytes // 4 + 4, dev, slot=5)
-        lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr.data_ptr(), 24, df.data_ptr(), dsb.data_ptr(), ws.data_ptr(),
-                          n, h, w, 24, s)
+        if CEM_BWD_FUSED:
+            # conv3's input gradient and the stencil bank's backward in one kernel: dt never reaches HBM (csrc/cem.hip)
+            nbytes = lib.cem_bwd_mid_workspace(n, h, w)
+            ws = scratch(nbytes // 4 + 4, dev, slot=5)
+            lib.cem_bwd_mid(dy3.data_ptr(), w3.data_ptr(), cs.data_ptr(), f.data_ptr(), dr.data_ptr(), df.data_ptr(), dsb.data_ptr(),
+                            ws.data_ptr(), n, h, w, s)
+        else:
+            dt = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
+            conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
+            nbytes = lib.sobel_add_bwd_workspace(n, h, w, 24)
+            ws = scratch(nbytes // 4 + 4, dev, slot=5)
+            lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr.data_ptr(), 24, df.data_ptr(), dsb.data_ptr(),
+                              ws.data_ptr(), n, h, w, 24, s)
         # BN2 + LeakyReLU
         dy2 = torch.empty_like(y2)
         dg2, db2 = grad_like(g2), grad_like(b2)

@@ -135,3 +135,33 @@ def test_fused_forward_inference_keeps_nothing():
         a = m(x)
     b = m(x)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 40), (1, 33, 17), (3, 5, 3), (1, 16, 16), (2, 130, 70)])
+def test_fused_backward_middle_matches_the_two_step_form(shape):
+    """mmi_cem_bwd_mid (conv3's input gradient + the stencil bank's backward in one kernel, dt and the D maps in LDS) against
+    mmi_conv_dgrad followed by mmi_sobel_add_bwd: dr, dfactor, dbias, on ragged tiles, a sub-tile image and many tiles per workgroup."""
+    from mmidet_hip import lib, ops
+    from mmidet_hip.ops import ConvDesc
+    n, h, w = shape
+    d = dev()
+    g = torch.Generator().manual_seed(h * 3 + w)
+    dy3 = torch.randn(n, h, w, 3, generator=g).to(d)
+    w3 = (torch.randn(3, 3, 3, 24, generator=g) * 0.2).to(d)          # OHWI [3][9][24]
+    cs = torch.randn(n, h, w, generator=g).to(d)
+    f = (torch.rand(24, generator=g) + 0.5).to(d)
+    s = torch.cuda.current_stream().cuda_stream
+    dt = torch.empty(n, h, w, 24, device=d)
+    ops.conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
+    dr0, df0, db0 = torch.empty_like(dt), torch.empty(24, device=d), torch.empty(24, device=d)
+    ws = torch.empty(lib.sobel_add_bwd_workspace(n, h, w, 24) // 4 + 4, device=d)
+    lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr0.data_ptr(), 24, df0.data_ptr(), db0.data_ptr(), ws.data_ptr(),
+                      n, h, w, 24, s)
+    dr1, df1, db1 = torch.empty_like(dt), torch.empty(24, device=d), torch.empty(24, device=d)
+    ws1 = torch.empty(lib.cem_bwd_mid_workspace(n, h, w) // 4 + 4, device=d)
+    lib.cem_bwd_mid(dy3.data_ptr(), w3.data_ptr(), cs.data_ptr(), f.data_ptr(), dr1.data_ptr(), df1.data_ptr(), db1.data_ptr(),
+                    ws1.data_ptr(), n, h, w, s)
+    torch.cuda.synchronize()
+    close(dr1, dr0, what='dr', tol=2e-6)
+    close(df1, df0, what='dfactor', tol=2e-5)
+    close(db1, db0, what='dbias', tol=2e-5)
