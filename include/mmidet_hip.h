@@ -379,8 +379,13 @@ int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_thres, float
  * dr (N,H,W,24; gradient of r), dfactor[24], dbias[24] (EnhanceConv2d's parameters), with dt and the eight D maps in LDS.
  * Replaces mmi_conv_dgrad(conv3) + mmi_sobel_add_bwd.  w3 = [3][9][24] (OHWI), chansum = the forward's channel-sum map. */
 size_t mmi_cem_bwd_mid_workspace(int N, int H, int W);
+/* y2 .. bn_partials all NULL, or all set: then BatchNorm2's backward REDUCTION rides along -- with y2 (conv2's raw output) and BN2's
+ * mean_invstd / gamma / beta the kernel also sums dz = dr * LeakyReLU'(z) and dz * xhat per channel into
+ * bn_partials[mmi_cem_bwd_mid_blocks(N,H,W)][2][24], the list mmi_bn_act_bwd_apply(y2, dr, ..., bn_partials, blocks, ...) folds. */
+int mmi_cem_bwd_mid_blocks(int N, int H, int W);
 int mmi_cem_bwd_mid(const float* dy3, const float* w3, const float* chansum, const float* factor, float* dr, float* dfactor,
-                    float* dbias, void* workspace, int N, int H, int W, void* stream);
+                    float* dbias, void* workspace, const float* y2, const float* mean_invstd2, const float* gamma2,
+                    const float* beta2, float* bn_partials, int N, int H, int W, void* stream);
 int mmi_cem_blocks(int N, int H, int W);
 int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_partials, int N, int H, int W, void* stream);
 int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const float* mean_invstd2, const float* gamma2, const float* beta2,

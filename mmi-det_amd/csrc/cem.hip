@@ -554,10 +554,16 @@ __global__ void sobel_bwd2_kernel(const float* __restrict__ dt, int ldd, const f
 // per scalar fetch.  The workgroups walk the tiles grid-stride and keep their dbias / dfactor partial sums in registers, so the
 // 48 wave reductions happen once per workgroup (partials[block][2][24] -> mmi_pair_colsum, as sobel_bwd1).
 // dt is zero outside the image (those positions hold no stencil output in the forward), dy3 likewise (zero padding).
-template <int OB>
+// BN = true additionally folds BatchNorm2's backward REDUCTION into the last phase: with y2 (conv2's raw output) and BN2's
+// mean / invstd / gamma / beta, dz = dr * LeakyReLU'(z) and the per-channel sums of dz and dz * xhat go to bn_partials[block][2][24]
+// (the layout mmi_bn_act_bwd_apply folds), so bn_bwd_reduce's pass over y2 and dr (1.26 GB) disappears.
+template <int OB, bool BN>
 __global__ __launch_bounds__(256) void cem_bwd_mid_kernel(const float* __restrict__ dy3, const float* __restrict__ w3,
                                                           const float* __restrict__ R, const float* __restrict__ factor,
-                                                          float* __restrict__ dr, float* __restrict__ partials, int N, int H, int W) {
+                                                          float* __restrict__ dr, float* __restrict__ partials,
+                                                          const float* __restrict__ y2, const float* __restrict__ mi2,
+                                                          const float* __restrict__ g2, const float* __restrict__ b2,
+                                                          float* __restrict__ bn_partials, int N, int H, int W) {
   constexpr int YS = TS + 4, DT = TS + 2;          // 20, 18
   __shared__ float dys[YS * YS * 3];
   __shared__ __align__(16) float dts[DT * DT * 24];
@@ -566,9 +572,11 @@ __global__ __launch_bounds__(256) void cem_bwd_mid_kernel(const float* __restric
   __shared__ float red[2][4][24];
   const int t = threadIdx.x;
   const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS, ntiles = tw * th * N;
-  float db[24], df[24];
+  float db[24], df[24], s1[BN ? 24 : 1], s2[BN ? 24 : 1];
 #pragma unroll
   for (int c = 0; c < 24; ++c) db[c] = df[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < (BN ? 24 : 1); ++c) s1[c] = s2[c] = 0.f;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tw * th), rr = tile - n * tw * th;
     const int h0 = (rr / tw) * TS, w0 = (rr % tw) * TS;
@@ -661,16 +669,29 @@ __global__ __launch_bounds__(256) void cem_bwd_mid_kernel(const float* __restric
       }
       const float add = stencils8_t(dn);
       stencils8(nb, st);
-      float* dst = dr + (((int64_t)n * H + oh) * W + ow) * 24;
+      const int64_t pix = ((int64_t)n * H + oh) * W + ow;
+      float* dst = dr + pix * 24;
 #pragma unroll
       for (int c = 0; c < 24; c += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(dts + q * 24 + c);
+        const f32x4 o4 = f32x4{v[0] + add, v[1] + add, v[2] + add, v[3] + add};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           db[c + k] += v[k];
           df[c + k] += v[k] * st[(c + k) & 7];
         }
-        *reinterpret_cast<f32x4*>(dst + c) = f32x4{v[0] + add, v[1] + add, v[2] + add, v[3] + add};
+        *reinterpret_cast<f32x4*>(dst + c) = o4;
+        if constexpr (BN) {
+          const f32x4 yy = *reinterpret_cast<const f32x4*>(y2 + pix * 24 + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {        // (the arithmetic of bn_bwd_reduce_kernel)
+            const float xh = (yy[k] - mi2[c + k]) * mi2[24 + c + k];
+            const float z = xh * g2[c + k] + b2[c + k];
+            const float dz = o4[k] * (z > 0.f ? 1.0f : 0.1f);
+            s1[c + k] += dz;
+            s2[c + k] += dz * xh;
+          }
+        }
       }
     }
   }
@@ -692,6 +713,27 @@ __global__ __launch_bounds__(256) void cem_bwd_mid_kernel(const float* __restric
   if (t < 48) {
     const int sidx = t / 24, c = t - sidx * 24;
     partials[((int64_t)blockIdx.x * 2 + sidx) * 24 + c] = red[sidx][0][c] + red[sidx][1][c] + red[sidx][2][c] + red[sidx][3][c];
+  }
+  if constexpr (BN) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 24; ++c) {
+      float a = s1[c], b = s2[c];
+#pragma unroll
+      for (int k = 32; k > 0; k >>= 1) {
+        a += __shfl_xor(a, k);
+        b += __shfl_xor(b, k);
+      }
+      if (lane == 0) {
+        red[0][wv][c] = a;
+        red[1][wv][c] = b;
+      }
+    }
+    __syncthreads();
+    if (t < 48) {
+      const int sidx = t / 24, c = t - sidx * 24;
+      bn_partials[((int64_t)blockIdx.x * 2 + sidx) * 24 + c] = red[sidx][0][c] + red[sidx][1][c] + red[sidx][2][c] + red[sidx][3][c];
+    }
   }
 }
 
@@ -825,15 +867,29 @@ extern "C" size_t mmi_cem_bwd_mid_workspace(int N, int H, int W) {
   return (size_t)(tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS) * 2 * 24 * sizeof(float);
 }
 
+extern "C" int mmi_cem_bwd_mid_blocks(int N, int H, int W) {
+  const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
+  return tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS;
+}
+
+// y2 .. bn_partials: all NULL, or all set -- then bn_partials[mmi_cem_bwd_mid_blocks][2][24] receives BatchNorm2's backward sums
+// (feed them to mmi_bn_act_bwd_apply(y2, dr, ..., bn_partials, blocks, ...)).
 extern "C" int mmi_cem_bwd_mid(const float* dy3, const float* w3, const float* chansum, const float* factor, float* dr, float* dfactor,
-                               float* dbias, void* workspace, int N, int H, int W, void* stream) {
+                               float* dbias, void* workspace, const float* y2, const float* mean_invstd2, const float* gamma2,
+                               const float* beta2, float* bn_partials, int N, int H, int W, void* stream) {
   MMI_CHECK_ARG(dy3 && w3 && chansum && factor && dr && dfactor && dbias && workspace && N > 0 && H > 0 && W > 0,
                 "mmi_cem_bwd_mid: bad arguments");
-  MMI_CHECK_ARG(((uintptr_t)dr & 15) == 0, "mmi_cem_bwd_mid: dr must be 16-byte aligned");
-  const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
-  const int blocks = tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS;
-  hipLaunchKernelGGL(cem_bwd_mid_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy3, w3, chansum, factor, dr,
-                     (float*)workspace, N, H, W);
+  const bool bn = y2 != nullptr;
+  MMI_CHECK_ARG(bn == (mean_invstd2 != nullptr) && bn == (gamma2 != nullptr) && bn == (beta2 != nullptr) && bn == (bn_partials != nullptr),
+                "mmi_cem_bwd_mid: the BatchNorm operands come all or none");
+  MMI_CHECK_ARG(((uintptr_t)dr & 15) == 0 && ((uintptr_t)y2 & 15) == 0, "mmi_cem_bwd_mid: dr / y2 must be 16-byte aligned");
+  const int blocks = mmi_cem_bwd_mid_blocks(N, H, W);
+  if (bn)
+    hipLaunchKernelGGL((cem_bwd_mid_kernel<2, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy3, w3, chansum, factor, dr,
+                       (float*)workspace, y2, mean_invstd2, gamma2, beta2, bn_partials, N, H, W);
+  else
+    hipLaunchKernelGGL((cem_bwd_mid_kernel<2, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy3, w3, chansum, factor, dr,
+                       (float*)workspace, y2, mean_invstd2, gamma2, beta2, bn_partials, N, H, W);
   MMI_CHECK_LAUNCH("mmi_cem_bwd_mid");
   return mmi_pair_colsum((float*)workspace, blocks, 24, dbias, dfactor, stream);  // (slot 0 -> dbias, slot 1 -> dfactor; consumes the partials)
 }

@@ -960,6 +960,7 @@ def sobel_add(r, factor, bias):
 
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
 CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
+CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "1") != "0"         # A/B: ... with BatchNorm2's backward reduction riding along
 
 
 class _CemFused(Function):
@@ -1027,8 +1028,10 @@ class _CemFused(Function):
             # conv3's input gradient and the stencil bank's backward in one kernel: dt never reaches HBM (csrc/cem.hip)
             nbytes = lib.cem_bwd_mid_workspace(n, h, w)
             ws = scratch(nbytes // 4 + 4, dev, slot=5)
+            bnpart = scratch(lib.cem_bwd_mid_blocks(n, h, w) * 48 + 64, dev, slot=7) if CEM_BWD_BN else None
             lib.cem_bwd_mid(dy3.data_ptr(), w3.data_ptr(), cs.data_ptr(), f.data_ptr(), dr.data_ptr(), df.data_ptr(), dsb.data_ptr(),
-                            ws.data_ptr(), n, h, w, s)
+                            ws.data_ptr(), *((y2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr())
+                                             if CEM_BWD_BN else (None,) * 5), n, h, w, s)
         else:
             dt = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
             conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
@@ -1039,7 +1042,12 @@ class _CemFused(Function):
         # BN2 + LeakyReLU
         dy2 = torch.empty_like(y2)
         dg2, db2 = grad_like(g2), grad_like(b2)
-        _bn_act_bwd(y2, 24, dr, 24, None, 0, 24, mi2, g2, b2, dy2, (dg2, db2, None, None), rows, 24, ACT_LEAKY, frozen, s)
+        if CEM_BWD_FUSED and CEM_BWD_BN:     # the reduction came out of cem_bwd_mid: fold its partials, then the apply pass
+            lib.bn_act_bwd_apply(y2.data_ptr(), 24, dr.data_ptr(), 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr(),
+                                 lib.cem_bwd_mid_blocks(n, h, w), dy2.data_ptr(), 24, dg2.data_ptr(), db2.data_ptr(), rows, 24, ACT_LEAKY,
+                                 frozen, s)
+        else:
+            _bn_act_bwd(y2, 24, dr, 24, None, 0, 24, mi2, g2, b2, dy2, (dg2, db2, None, None), rows, 24, ACT_LEAKY, frozen, s)
         # conv2: x (3) -> y2 (24)
         d2 = ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, ldx, 24)
         dw2 = _wgrad(dy2, 24, x, ldx, w2, d2, overlap=OVERLAP_WGRAD)

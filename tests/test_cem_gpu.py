@@ -160,8 +160,29 @@ def test_fused_backward_middle_matches_the_two_step_form(shape):
     dr1, df1, db1 = torch.empty_like(dt), torch.empty(24, device=d), torch.empty(24, device=d)
     ws1 = torch.empty(lib.cem_bwd_mid_workspace(n, h, w) // 4 + 4, device=d)
     lib.cem_bwd_mid(dy3.data_ptr(), w3.data_ptr(), cs.data_ptr(), f.data_ptr(), dr1.data_ptr(), df1.data_ptr(), db1.data_ptr(),
-                    ws1.data_ptr(), n, h, w, s)
+                    ws1.data_ptr(), None, None, None, None, None, n, h, w, s)
     torch.cuda.synchronize()
     close(dr1, dr0, what='dr', tol=2e-6)
     close(df1, df0, what='dfactor', tol=2e-5)
     close(db1, db0, what='dbias', tol=2e-5)
+    # the same launch with BatchNorm2's backward reduction riding along: partials -> mmi_bn_act_bwd_apply, against the one-call
+    # BatchNorm backward on the same dr
+    y2 = torch.randn(n, h, w, 24, generator=g).to(d)
+    mi = torch.cat([torch.randn(24, generator=g) * 0.2, torch.rand(24, generator=g) + 0.5]).to(d)
+    gam, bet = (torch.rand(24, generator=g) + 0.5).to(d), (torch.randn(24, generator=g) * 0.2).to(d)
+    rows = n * h * w
+    dy_ref, dg_ref, dbt_ref = torch.empty_like(y2), torch.empty(24, device=d), torch.empty(24, device=d)
+    ops._bn_act_bwd(y2, 24, dr0, 24, None, 0, 24, mi, gam, bet, dy_ref, (dg_ref, dbt_ref, None, None), rows, 24, ops.ACT_LEAKY, 0, s)
+    nblk = lib.cem_bwd_mid_blocks(n, h, w)
+    part = torch.empty(nblk * 48 + 64, device=d)
+    dr2 = torch.empty_like(dt)
+    lib.cem_bwd_mid(dy3.data_ptr(), w3.data_ptr(), cs.data_ptr(), f.data_ptr(), dr2.data_ptr(), df1.data_ptr(), db1.data_ptr(),
+                    ws1.data_ptr(), y2.data_ptr(), mi.data_ptr(), gam.data_ptr(), bet.data_ptr(), part.data_ptr(), n, h, w, s)
+    dy_got, dg_got, dbt_got = torch.empty_like(y2), torch.empty(24, device=d), torch.empty(24, device=d)
+    lib.bn_act_bwd_apply(y2.data_ptr(), 24, dr2.data_ptr(), 24, mi.data_ptr(), gam.data_ptr(), bet.data_ptr(), part.data_ptr(), nblk,
+                         dy_got.data_ptr(), 24, dg_got.data_ptr(), dbt_got.data_ptr(), rows, 24, ops.ACT_LEAKY, 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dr2, dr1)
+    close(dg_got, dg_ref, what='dgamma2', tol=2e-5)
+    close(dbt_got, dbt_ref, what='dbeta2', tol=2e-5)
+    close(dy_got, dy_ref, what='dy2', tol=2e-5)
