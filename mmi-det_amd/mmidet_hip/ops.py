@@ -960,7 +960,9 @@ def sobel_add(r, factor, bias):
 
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
 CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
-CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "1") != "0"         # A/B: ... with BatchNorm2's backward reduction riding along
+# ... with BatchNorm2's backward reduction riding along: correct (tests/test_cem_gpu.py) but 48 more accumulators cost the kernel a
+# workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
+CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "0") == "1"
 
 
 class _CemFused(Function):
