@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void smallconv_kernel(const float* __restrict_
 // a thread owns one (tap, wide-channel) pair and the three narrow channels, so a pixel costs it one 16-byte LDS read of the
 // narrow operand (padded to 4 floats; the dy form is a wave-wide broadcast) plus one 4-byte read of the wide one for three
 // FMAs -- a third of the LDS instructions of the output-per-thread form, which was LDS-issue bound.
-template <int CIN, int COUT>
+// Round 2: the next tile's operands are fetched into registers while the current tile is being multiplied (the wide operand
+// with 16-byte loads when VEC), and the three narrow channels of a pixel cost two VALU instructions -- one packed FMA
+// (v_pk_fma_f32, the wide value broadcast to both halves) + one FMA -- instead of three.
+template <int CIN, int COUT, bool VEC>
 __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ dy, int ldy,
                                                               float* __restrict__ partials, int N, int H, int W) {
@@ -97,54 +100,100 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __res
   constexpr int WIDE = XN ? COUT : CIN;            // 24
   constexpr int NOUT = COUT * 9 * CIN;
   constexpr int XE = XN ? 4 : CIN, DE = XN ? COUT : 4;   // floats per pixel in LDS
-  __shared__ __align__(16) float xs[(TS + 2) * (TS + 2) * XE];
-  __shared__ __align__(16) float ds[TS * TS * DE];
+  constexpr int XP = (TS + 2) * (TS + 2), DP = TS * TS;  // pixels of the two tiles (x with its halo)
+  constexpr int WP = XN ? DP : XP, NP_ = XN ? XP : DP;   // pixels of the wide / narrow tile
+  constexpr int WV = (WP * 6 + 255) / 256;               // 16-byte pieces of the wide tile per thread
+  constexpr int NV = (NP_ + 255) / 256;                  // narrow pixels per thread
+  __shared__ __align__(16) float xs[XP * XE];
+  __shared__ __align__(16) float ds[DP * DE];
   const int t = threadIdx.x;
   const bool owner = t < 9 * WIDE;
   const int tap = owner ? t / WIDE : 0, wc = owner ? t - tap * WIDE : 0;
   const int xoff = ((tap / 3) * (TS + 2) + tap % 3) * XE + (XN ? 0 : wc);   // of the tap, relative to the pixel
-  float acc[3] = {0.f, 0.f, 0.f};
+  f32x2 acc01 = {0.f, 0.f};
+  float acc2 = 0.f;
   const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
   const int ntiles = tw * th * N;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const float* wsrc = XN ? dy : x;
+  const float* nsrc = XN ? x : dy;
+  const int ldw = XN ? ldy : ldx, ldn = XN ? ldx : ldy;
+  f32x4 wreg[WV];
+  float nreg[NV][3];
+  auto gload = [&](int tile) {
     const int n = tile / (tw * th), r = tile - n * tw * th;
     const int h0 = (r / tw) * TS, w0 = (r % tw) * TS;
-    __syncthreads();
-    for (int e = t; e < (TS + 2) * (TS + 2) * XE; e += 256) {
-      const int c = e % XE, p = e / XE;
-      const int ih = h0 + p / (TS + 2) - 1, iw = w0 + p % (TS + 2) - 1;
-      xs[e] = (c < CIN && ih >= 0 && iw >= 0 && ih < H && iw < W) ? x[(((int64_t)n * H + ih) * W + iw) * ldx + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = t + i * 256, p = v / 6, c4 = (v - p * 6) * 4;
+      wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (v < WP * 6) {
+        const int ih = XN ? h0 + p / TS : h0 + p / (TS + 2) - 1, iw = XN ? w0 + p % TS : w0 + p % (TS + 2) - 1;
+        if (ih >= 0 && iw >= 0 && ih < H && iw < W) {
+          const float* src = wsrc + (((int64_t)n * H + ih) * W + iw) * ldw + c4;
+          if (VEC) wreg[i] = *reinterpret_cast<const f32x4*>(src);
+          else wreg[i] = f32x4{src[0], src[1], src[2], src[3]};
+        }
+      }
     }
-    for (int e = t; e < TS * TS * DE; e += 256) {
-      const int c = e % DE, p = e / DE;
-      const int oh = h0 + p / TS, ow = w0 + p % TS;
-      ds[e] = (c < COUT && oh < H && ow < W) ? dy[(((int64_t)n * H + oh) * W + ow) * ldy + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int p = t + i * 256;
+      nreg[i][0] = nreg[i][1] = nreg[i][2] = 0.f;
+      if (p < NP_) {
+        const int ih = XN ? h0 + p / (TS + 2) - 1 : h0 + p / TS, iw = XN ? w0 + p % (TS + 2) - 1 : w0 + p % TS;
+        if (ih >= 0 && iw >= 0 && ih < H && iw < W) {
+          const float* src = nsrc + (((int64_t)n * H + ih) * W + iw) * ldn;
+          nreg[i][0] = src[0];
+          nreg[i][1] = src[1];
+          nreg[i][2] = src[2];
+        }
+      }
     }
+  };
+  auto lstore = [&]() {
+    float* wdst = XN ? ds : xs;
+    float* ndst = XN ? xs : ds;
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = t + i * 256;
+      if (v < WP * 6) *reinterpret_cast<f32x4*>(wdst + v * 4) = wreg[i];      // [pixel][24]: piece v lies at float 4 v
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int p = t + i * 256;
+      if (p < NP_) *reinterpret_cast<f32x4*>(ndst + p * 4) = f32x4{nreg[i][0], nreg[i][1], nreg[i][2], 0.f};
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) gload(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                       // the previous tile has been consumed
+    lstore();
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);      // in flight during the multiply below
     if (owner) {
       for (int pr = 0; pr < TS; ++pr) {
         const float* xrow = xs + pr * (TS + 2) * XE + xoff;
         const float* drow = ds + pr * TS * DE;
 #pragma unroll
         for (int pc = 0; pc < TS; ++pc) {
+          f32x4 nv;
+          float wv;
           if (XN) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + pc * 4);
-            const float dv = drow[pc * DE + wc];
-            acc[0] += dv * xv[0];
-            acc[1] += dv * xv[1];
-            acc[2] += dv * xv[2];
+            nv = *reinterpret_cast<const f32x4*>(xrow + pc * 4);
+            wv = drow[pc * DE + wc];
           } else {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(drow + pc * 4);
-            const float xv = xrow[pc * XE];
-            acc[0] += dv[0] * xv;
-            acc[1] += dv[1] * xv;
-            acc[2] += dv[2] * xv;
+            nv = *reinterpret_cast<const f32x4*>(drow + pc * 4);
+            wv = xrow[pc * XE];
           }
+          acc01 += f32x2{wv, wv} * f32x2{nv[0], nv[1]};
+          acc2 += wv * nv[2];
         }
       }
     }
   }
   if (owner) {
+    const float acc[3] = {acc01[0], acc01[1], acc2};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int co = XN ? wc : k, ci = XN ? k : wc;
@@ -776,10 +825,17 @@ int mmi_smallconv_wgrad(const float* dy, const float* x, float* dw, void* worksp
   const int blocks = mmi_smallconv_blocks(d) < WG_BLOCKS ? mmi_smallconv_blocks(d) : WG_BLOCKS;
   const int nout = d->Cout * 9 * d->Cin;
   float* part = (float*)workspace;
-  if (d->Cin == 3)
-    hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
-  else
-    hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+  if (d->Cin == 3) {      // (VEC: the 24-channel operand fetched with 16-byte loads)
+    if (d->ldy % 4 == 0 && ((uintptr_t)dy & 15) == 0)
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+    else
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+  } else {
+    if (d->ldx % 4 == 0 && ((uintptr_t)x & 15) == 0)
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+    else
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+  }
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel)");
   hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(nout, 16)), dim3(256), 0, s, (const float*)part, blocks, nout, dw);
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel reduce)");
