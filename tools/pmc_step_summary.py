@@ -11,7 +11,7 @@ import sys
 csv.field_size_limit(1 << 30)
 
 FAMILIES = [('igemm', r'igemm_kernel|wgrad_kernel|slab_reduce'), ('bn', r'bn_act_fwd|bn_bwd|bn_finalize|stat_fold|pair_fold|pair_finalize'),
-            ('cem', r'smallconv|sobel|chansum'), ('tokens', r'layernorm|attn_|gelu|dropout|sigmoid|mul_kernel|scale_kernel'),
+            ('cem', r'smallconv|sobel|chansum|cem_'), ('tokens', r'layernorm|attn_|gelu|dropout|sigmoid|mul_kernel|scale_kernel'),
             ('fusion', r'avgpool8|upsample_add|fusion_stats|ffm_|separation'), ('spp', r'spp_'), ('optimizer', r'sgd_ema'),
             ('aten', r'at::native|rocclr'), ('other', r'.')]
 
