@@ -963,6 +963,7 @@ def sobel_add(r, factor, bias):
 
 
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
+CEM_WGRAD_LATE = __import__("os").environ.get("MMIDET_CEM_WGRAD_LATE", "1") != "0"   # A/B: conv3's wgrad after the critical chain
 CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
 # ... with BatchNorm2's backward reduction riding along: correct (tests/test_cem_gpu.py) but 48 more accumulators cost the kernel a
 # workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
@@ -1026,7 +1027,11 @@ class _CemFused(Function):
         _bn_act_bwd(y3, 3, dout, ldd, None, 0, 3, mi3, g3, b3, dy3, (dg3, db3, None, None), rows, 3, ACT_LEAKY, frozen, s)
         # conv3: t (24) -> y3 (3)
         d3 = ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3)
-        dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
+        # conv3's weight gradient is independent of everything below.  Launched here it shares the chip with the critical chain
+        # (dr -> BatchNorm2 backward -> conv2's weight gradient) and stretches it: cem_bwd_mid 0.29 -> 0.57 ms, the BatchNorm
+        # reduction 0.31 -> 0.58 ms in the step's trace.  Launched LAST it runs beside conv2's weight gradient on the other wgrad
+        # stream, where nothing is waiting for either (MMIDET_CEM_WGRAD_LATE=0: the old order).
+        dw3 = None if CEM_WGRAD_LATE else _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
         dr = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
         df = torch.empty(24, dtype=torch.float32, device=dev)
         dsb = grad_like(sbias)
@@ -1057,6 +1062,8 @@ class _CemFused(Function):
         # conv2: x (3) -> y2 (24)
         d2 = ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, ldx, 24)
         dw2 = _wgrad(dy2, 24, x, ldx, w2, d2, overlap=OVERLAP_WGRAD)
+        if dw3 is None:
+            dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
