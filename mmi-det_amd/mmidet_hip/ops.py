@@ -963,7 +963,7 @@ def sobel_add(r, factor, bias):
 
 
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
-CEM_WGRAD_LATE = __import__("os").environ.get("MMIDET_CEM_WGRAD_LATE", "1") != "0"   # A/B: conv3's wgrad after the critical chain
+CEM_WGRAD_LATE = __import__("os").environ.get("MMIDET_CEM_WGRAD_LATE", "0") == "1"   # A/B: conv3's wgrad after the critical chain (no gain)
 CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
 # ... with BatchNorm2's backward reduction riding along: correct (tests/test_cem_gpu.py) but 48 more accumulators cost the kernel a
 # workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
@@ -1030,7 +1030,8 @@ class _CemFused(Function):
         # conv3's weight gradient is independent of everything below.  Launched here it shares the chip with the critical chain
         # (dr -> BatchNorm2 backward -> conv2's weight gradient) and stretches it: cem_bwd_mid 0.29 -> 0.57 ms, the BatchNorm
         # reduction 0.31 -> 0.58 ms in the step's trace.  Launched LAST it runs beside conv2's weight gradient on the other wgrad
-        # stream, where nothing is waiting for either (MMIDET_CEM_WGRAD_LATE=0: the old order).
+        # stream, where nothing is waiting for either.  Measured in the step (three interleaved pairs): 122.46 vs 122.55 ms, i.e. nothing --
+        # MMIDET_CEM_WGRAD_LATE=1 keeps the variant, the default is the original order.
         dw3 = None if CEM_WGRAD_LATE else _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
         dr = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
         df = torch.empty(24, dtype=torch.float32, device=dev)
