@@ -145,3 +145,33 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert r.returncode != 0
     assert r.stderr.count('bench.py needs an MI355X') >= 2 or 'invalid device ordinal' in r.stderr, r.stderr[-3000:]
     assert '--gpus 2 but WORLD_SIZE' not in r.stderr
+
+
+def test_fan_out_plan_of_the_default_graph():
+    """yolo_test._plan_lanes: every saved map of the yolov5l two-stream-fourier graph that has exactly two consumers is handed
+    on by its first consumer (Conv, the fusion transformers' token pooling, nn.Upsample), so no gradient fan-out is left to the
+    autograd engine: 16 maps, first consumers of the three kinds, and the plan is dropped by fuse() and survives pickling."""
+    import pickle
+    import sys
+    sys.path[:0] = [REPO, os.path.join(REPO, 'mmi-det_amd')]
+    import bench
+    from models.common import GPT, Conv
+    from models.yolo_test import Model, Upsample2x
+    m = Model(bench.load_cfg('l_fourier'))
+    plan = m._fan_skip
+    assert sum(len(v) for v in plan.values()) == 16
+    kinds = {type(m.model[i]).__name__ for i in plan}
+    assert kinds == {'Conv', 'GPT', 'GPT1_fourier', 'Upsample2x'}, kinds
+    for first, srcs in plan.items():
+        layer = m.model[first]
+        assert isinstance(layer, (Conv, GPT, Upsample2x)) and getattr(layer, 'fan_skip', False)
+        for j in srcs:
+            consumers = [l.i for l in m.model if j in m._srcs[l.i]]
+            assert len(consumers) == 2 and consumers[0] == first, (j, consumers)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2._fan_skip == plan
+    old = dict(m2.__dict__)
+    old.pop('_fan_skip')                 # an object pickled by an older build: the plan is rebuilt on load
+    m3 = Model.__new__(Model)
+    m3.__setstate__(old)
+    assert m3._fan_skip == plan
