@@ -147,7 +147,7 @@ _side_rr = 0
 # a replaced table is kept until the side streams have been joined); neither explains a fault.  Until it is understood the
 # value 1 is refused rather than left as a trap.
 NSIDE = int(__import__('os').environ.get('MMIDET_NSIDE', '2'))
-if NSIDE < 2:
+if NSIDE < 2 and __import__('os').environ.get('MMIDET_NSIDE_UNSAFE') != '1':
     raise RuntimeError('MMIDET_NSIDE=%d: one wgrad stream per lane is a known-bad setting (see mmidet_hip/ops.py); use 2 or 3' % NSIDE)
 _pending = []
 _pending_sides = {}
