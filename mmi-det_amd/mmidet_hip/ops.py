@@ -140,15 +140,14 @@ _side_streams = {}
 _side_rr = 0
 # wgrad side streams per lane, used round-robin: two let a small weight-gradient GEMM (token projections, 1x1 convs) run beside
 # a large one instead of behind it (125.3 -> 123.4 ms/step; three are worse: 127.9)
-# KNOWN ISSUE (round 2, not root-caused): MMIDET_NSIDE=1 -- every wgrad of a lane behind one another on a single side stream --
-# ended in a GPU memory access fault in the first warm-up step, three runs out of three (gpurun_out/r2_nside1.err); 2 (the
-# default) and 3 pass the whole GPU suite and the run-to-run bit-identity checks (tools/det_grads.py).  Two ordering gaps
-# found while looking for it are closed in wgrad_table() (a table shared by the two lanes is now ordered behind its build;
-# a replaced table is kept until the side streams have been joined); neither explains a fault.  Until it is understood the
-# value 1 is refused rather than left as a trap.
-NSIDE = int(__import__('os').environ.get('MMIDET_NSIDE', '2'))
-if NSIDE < 2 and __import__('os').environ.get('MMIDET_NSIDE_UNSAFE') != '1':
-    raise RuntimeError('MMIDET_NSIDE=%d: one wgrad stream per lane is a known-bad setting (see mmidet_hip/ops.py); use 2 or 3' % NSIDE)
+# (Round 2: MMIDET_NSIDE=1 -- every wgrad of a lane behind one another on one stream -- used to end in a GPU memory access fault in
+#  the first warm-up step, three runs of three.  Cause: the pixel tables of wgrad_table() are shared by the two backbone lanes
+#  (same geometries), and the lane that did NOT build a table used it without being ordered behind the other lane's build kernel
+#  -- in the first step a wgrad could walk a table that was still uninitialised memory; likewise a table replaced by a larger one
+#  was freed while a queued wgrad could still read it.  Both gaps are closed in wgrad_table(); with them closed the setting runs
+#  (122.07 ms/step, gpurun_out/r2_nside1b.json) and tests/test_step_gpu.py covers it.  The default was exposed to the same race;
+#  two wgrad streams per lane merely made the window small.)
+NSIDE = max(1, int(__import__('os').environ.get('MMIDET_NSIDE', '2')))
 _pending = []
 _pending_sides = {}
 

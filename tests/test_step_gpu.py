@@ -390,3 +390,20 @@ def test_early_optimizer_is_the_same_training():
     for k in e1:
         assert torch.equal(e1[k], e2[k]), 'ema ' + k
     assert ts1.optimizer.updates == ts2.optimizer.updates == 4
+
+
+def test_one_wgrad_stream_per_lane_is_the_same_training(monkeypatch):
+    """MMIDET_NSIDE=1 (all weight gradients of a lane behind one another on ONE side stream) faulted until the shared pixel
+    tables were ordered behind their build across lanes (ops.wgrad_table): the launch structure changes, the numbers do not."""
+    from mmidet_hip import ops
+    m2, ts2, cfg = make()
+    batches = [batch(cfg, 80 + i) for i in range(3)]
+    ref = [ts2.step(*b)[0].clone() for b in batches]
+    monkeypatch.setattr(ops, 'NSIDE', 1)
+    m1, ts1, _ = make()
+    for b, l2 in zip(batches, ref):
+        l1, _ = ts1.step(*b)
+        assert torch.equal(l1, l2)
+    torch.cuda.synchronize()
+    for (k, a), (_, bb) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, bb), k
