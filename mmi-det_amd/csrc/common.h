@@ -69,6 +69,12 @@ struct StatFold {
   int* cnt;
   int nrows, C, nct, G;
 };
+// Publishing hand-off used by every last-arriver fold (MI355X_MICROARCH.md, "inter-workgroup visibility", first row of the
+// sc1 hand-off table): payload stored with sc1 (st_agent) -> EVERY storing wave waits for its own stores (this call) ->
+// workgroup barrier -> one lane's agent-scope atomic add; the workgroup whose add came last reads with sc1 loads (ld_agent)
+// behind a workgroup barrier.  A workgroup-scope release fence is NOT enough here: on gfx950 it lowers to lgkmcnt(0) only
+// and leaves the global stores in flight (round-2 advisor finding).  Inline asm so that no compiler pass can drop the wait.
+__device__ __forceinline__ void mmi_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -119,7 +125,7 @@ __device__ __forceinline__ bool stat_arrive(const StatFold& f, int row, int ct, 
   const int t = threadIdx.x;
   const int ngroups = (f.nrows + f.G - 1) / f.G;
   const int g = row / f.G, r0 = g * f.G, r1 = min(r0 + f.G, f.nrows);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed (they are write-through)
+  mmi_drain_stores();  // every storing wave: its sc1 (write-through) stores have left the CU before the barrier below
   __syncthreads();
   if (t == 0) {
     int* c = f.cnt + g * f.nct + ct;
@@ -134,7 +140,7 @@ __device__ __forceinline__ bool stat_arrive(const StatFold& f, int row, int ct, 
     st_agent(f.l1 + ((int64_t)g * 2 + 0) * f.C + c0 + t, (float)s1);
     st_agent(f.l1 + ((int64_t)g * 2 + 1) * f.C + c0 + t, (float)s2);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  mmi_drain_stores();  // every storing wave: its sc1 (write-through) stores have left the CU before the barrier below
   __syncthreads();
   if (t == 0) {
     int* c = f.cnt + ngroups * f.nct + ct;

@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 256 + t, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed
+      mmi_drain_stores();  // every storing wave: its sc1 (write-through) stores have left the CU before the barrier below
       __syncthreads();
       const int lo = tile * nk;
       const int b_first = sk.owner(lo), b_last = sk.owner(lo + nk - 1);
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   int* cnt = p.cnt + (int64_t)tile * p.cnt_per_tile;
   while (true) {
     const int group = node >> 2, gfirst = group << 2, gsize = min(4, nodes - gfirst);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's (write-through) stores have completed
+    mmi_drain_stores();  // every storing wave: its sc1 (write-through) stores have left the CU before the barrier below
     __syncthreads();
     if (t == 0) {
       const int last = __hip_atomic_fetch_add(cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
