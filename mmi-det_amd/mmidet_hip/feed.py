@@ -35,11 +35,12 @@ class PairedBatchFeeder:
         self.bytes_copied = 0
 
     @staticmethod
-    def _fit(buf, t, **kw):
-        """A buffer of at least t.numel() elements of t's dtype (grow-only), viewed with t's shape."""
+    def _fit(buf, t, headroom=1.0, **kw):
+        """(buffer of at least t.numel() elements of t's dtype (grow-only), whether it was (re)allocated).  `headroom` > 1 sizes
+        a new buffer generously (the target list changes length from batch to batch: no regrowth per batch)."""
         if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
-            buf = torch.empty(max(t.numel(), 1), dtype=t.dtype, **kw)
-        return buf
+            return torch.empty(max(int(t.numel() * headroom), 1), dtype=t.dtype, **kw), True
+        return buf, False
 
     def _stage(self, k, batch):
         imgs, targets = batch[0], batch[1]
@@ -50,10 +51,16 @@ class PairedBatchFeeder:
         s = self.slots[k]
         if s.ready is not None:
             s.ready.synchronize()               # the copy that last read this slot's pinned buffers has completed
-        s.pin_img = self._fit(s.pin_img, imgs, pin_memory=True)
-        s.pin_tgt = self._fit(s.pin_tgt, targets, pin_memory=True)
-        s.dev_img = self._fit(s.dev_img, imgs, device=self.device)
-        s.dev_tgt = self._fit(s.dev_tgt, targets, device=self.device)
+        s.pin_img, _ = self._fit(s.pin_img, imgs, pin_memory=True)
+        s.pin_tgt, _ = self._fit(s.pin_tgt, targets, headroom=2.0, pin_memory=True)
+        s.dev_img, new_i = self._fit(s.dev_img, imgs, device=self.device)
+        s.dev_tgt, new_t = self._fit(s.dev_tgt, targets, headroom=2.0, device=self.device)
+        if new_i or new_t:
+            # A fresh device buffer comes from the caching allocator of the COMPUTE stream (the stream current here): the block
+            # may be one the host has already freed while kernels queued on the compute stream still use it.  Its first write is
+            # the copy below, on the copy stream, so that copy must be ordered behind everything the compute stream has queued
+            # (later uses of the slot are ordered by `free`).
+            self.copy_stream.wait_stream(torch.cuda.current_stream())
         pi, pt = s.pin_img[:imgs.numel()].view(imgs.shape), s.pin_tgt[:targets.numel()].view(targets.shape)
         pi.copy_(imgs)                          # (a loader with pin_memory=True makes this a pinned -> pinned memcpy)
         pt.copy_(targets)

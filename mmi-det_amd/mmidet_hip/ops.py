@@ -193,21 +193,23 @@ def wgrad_table(d, device):
     g = (device, d.N, d.H, d.W, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad, d.ldx)
     ent = _wgrad_tabs.get(g)
     cur = _stream()
-    capturing = torch.cuda.is_current_stream_capturing()
+    if torch.cuda.is_current_stream_capturing():
+        # Never build inside a capture (the build would be a node of ONE lane, the other lane's use in the same graph would not be
+        # ordered behind it, and the table would live in the graph's private pool while this cache outlives the graph).  A table
+        # built by the warm-up steps is a constant by now (capture follows a device synchronisation); a geometry first seen
+        # here takes the kernel's own slab-by-slab builder, which gives bit-identical results.
+        return ent[0] if ent is not None and ent[0].numel() >= nb else None
     if ent is None or ent[0].numel() < nb:
         if ent is not None:
             _retired.append(ent[0])      # a queued wgrad on a side stream may still read the smaller table (see scratch())
         t = torch.empty(nb, dtype=torch.uint8, device=device)
         lib.conv_wgrad_table_build(t.data_ptr(), d, cur)
-        ev = None
-        if not capturing:                # (a build inside a capture is a node of the graph, ordered like any kernel)
-            ev = torch.cuda.Event()
-            ev.record()
+        ev = torch.cuda.Event()
+        ev.record()
         ent = _wgrad_tabs[g] = (t, ev, {cur})
-    elif cur not in ent[2] and ent[1] is not None and not capturing:
+    elif cur not in ent[2]:
         # The twin backbones share geometries, hence tables: the lane that did not build this one orders itself behind the
-        # build (once per stream; afterwards the table is constant).  Not while capturing: the capture follows warm-up steps
-        # and a device synchronisation, and a wait on an event from outside the capture would be an unjoined dependency.
+        # build (once per stream; afterwards the table is constant).
         torch.cuda.current_stream().wait_event(ent[1])
         ent[2].add(cur)
     return ent[0]

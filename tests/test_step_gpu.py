@@ -11,14 +11,18 @@ from test_ops_gpu import close, dev
 pytestmark = pytest.mark.gpu
 
 
-def make(kind='fourier', dropout=0.0, **kw):
+def make(kind='fourier', dropout=0.0, width=None, **kw):
     from mmidet_hip.train_step import TrainStep
     from models.yolo_test import Model
     from oracle import portable_init
     from oracle.ref_model import Model as OModel
     cfg = tiny_cfg(kind)
+    if width is not None:
+        cfg['width_multiple'] = width
+        if kind == 'fourier':
+            cfg['backbone'][6][3] = [int(128 * width)]
     sd = portable_init.fill_(OModel(cfg).state_dict())
-    m = Model(tiny_cfg(kind))
+    m = Model(copy.deepcopy(cfg))
     m.load_state_dict(sd, strict=True)
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
@@ -390,6 +394,35 @@ def test_early_optimizer_is_the_same_training():
     for k in e1:
         assert torch.equal(e1[k], e2[k]), 'ema ' + k
     assert ts1.optimizer.updates == ts2.optimizer.updates == 4
+
+
+@pytest.mark.parametrize('nside', [1, 2])
+def test_first_step_orders_the_shared_wgrad_tables_across_lanes(monkeypatch, nside):
+    """The round-2 GPU fault (MMIDET_NSIDE=1): the twin backbone lanes share the per-geometry pixel tables of the wgrad loaders,
+    and the lane that did not build a table used it without being ordered behind the other lane's build kernel.  The race is
+    reachable only on a geometry's FIRST use, so the process-global table cache is emptied first (round 2's test ran a warm
+    model beforehand and could not fail); widths 32..512 so that the 3x3 layers of both lanes take tables.  Checked: tables were
+    built, at least one was used by a second stream that had to wait for the build event (ops.wgrad_table), and the step is
+    bit-identical to the step of a model that finds every table built and long finished."""
+    from mmidet_hip import ops
+    monkeypatch.setattr(ops, 'NSIDE', nside)
+    monkeypatch.setenv('MMIDET_TWIN', '0')            # the twin-lane launch form has one launch per layer pair: no second lane
+    torch.cuda.synchronize()
+    ops._wgrad_tabs.clear()
+    ops._wgrad_tab_use.clear()
+    m1, ts1, cfg = make(width=0.5)
+    b = batch(cfg, 80)
+    l1, _ = ts1.step(*b)
+    torch.cuda.synchronize()
+    assert ops._wgrad_tabs, 'no wgrad of this graph took a pixel table: the test does not reach the code it is for'
+    waited = [g for g, ent in ops._wgrad_tabs.items() if len(ent[2]) >= 2]
+    assert waited, 'no table was shared by two streams: the cross-lane ordering did not run'
+    m2, ts2, _ = make(width=0.5)                      # every table exists and its build finished long ago
+    l2, _ = ts2.step(*b)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2)
+    for (k, a), (_, bb) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, bb), k
 
 
 def test_one_wgrad_stream_per_lane_is_the_same_training(monkeypatch):

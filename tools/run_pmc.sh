@@ -9,6 +9,6 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY 
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -o p -- python3 $R/tools/pmc_conv.py "$@" > $R/gpurun_out/pmc_${tag}_$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -o p -- python3 $R/tools/pmc_conv.py "$@" > $R/gpurun_out/pmc_${tag}_$i.log 2>&1 || { echo "pass $i failed: stopping (see gpurun_out/pmc_${tag}_$i.log)"; tail -n 20 $R/gpurun_out/pmc_${tag}_$i.log; exit 1; }
 done
 ls $R/gpurun_out/pmc_${tag}_1 | head
