@@ -1,0 +1,159 @@
+// Launchers of igemm_kernel: one explicit instantiation per (DGRAD, EPI) pair and translation unit.
+#pragma once
+#include "igemm_kernel.h"
+
+namespace mmi_ig {
+
+// Resident workgroups per CU of a stream-K kernel variant (registers and LDS decide; 3 by the launch bound).
+template <bool DGRAD>
+int sk_occupancy(int bn) {
+  static int cache[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  int& c = cache[g_gemm_prec][bn == 128 ? 1 : 0];
+  if (c == 0) {
+    int n = 0;
+    hipError_t e;
+#define OCC(P_) (bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, P_>, 256, 0) \
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, P_>, 256, 0))
+    // (fp32: the uniform-tap variant is what nearly every stream-K shape runs; the few others fit its grid as well)
+    if (g_gemm_prec == 0 && g_uniform_loaders)
+      e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 0, false, true>, 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 0, false, true>, 256, 0);
+    else
+      e = g_gemm_prec == 0 ? OCC(0) : (g_gemm_prec == 1 ? OCC(1) : (g_gemm_prec == 2 ? OCC(2) : OCC(3)));
+#undef OCC
+    c = (e == hipSuccess && n > 0) ? n : (g_gemm_prec >= 2 ? 2 : 3);
+    (void)hipGetLastError();
+  }
+  return c;
+}
+
+template <bool DGRAD, bool EPI>
+int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s,
+                 size_t slot_offset) {
+  const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
+  IgemmP p = p0;
+  p.zero = zero_src();
+  if (p.zero == nullptr) {
+    mmi_set_error("igemm: cannot resolve the zero-source symbol");
+    return MMI_ERR_LAUNCH;
+  }
+  p.mtiles = f.mtiles;
+  p.ntiles = f.ntiles;
+  // uniform-tap loaders (igemm_kernel<..., UNI>): whole slabs inside one tap, tap table in 32 bits, 31-bit byte offsets
+  bool uni = false;
+  if (vec && g_uniform_loaders && g_gemm_prec == 0 && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
+    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;
+    const int64_t npix = (int64_t)(p.M / ((int64_t)p.P * p.Q)) * p.Hs * p.Ws;
+    const int64_t a_bytes = (margin + (npix - 1) * p.lda + p.Kc) * 4;
+    const int64_t b_bytes = DGRAD ? (int64_t)p.Kc * p.ldb * 4 : (int64_t)p.Ncol * p.ldb * 4;
+    if (a_bytes < (1LL << 31) && b_bytes < (1LL << 31)) {
+      uni = true;
+      p.a_bytes = (uint32_t)a_bytes;
+      p.b_bytes = (uint32_t)b_bytes;
+      const int64_t c_bytes = ((int64_t)(p.M - 1) * p.ldc + p.Ncol) * 4;
+      p.c_bytes = c_bytes < (1LL << 31) ? (uint32_t)c_bytes : 0u;
+    }
+  }
+  if (f.sk_grid > 0) {
+    if (workspace == nullptr || workspace_bytes < slot_offset + sk_slot_bytes(f) || ((uintptr_t)workspace & 15)) {
+      mmi_set_error("%s: this shape runs the stream-K schedule and needs a 16-byte aligned workspace of %zu bytes (got %zu)",
+                    who, slot_offset + sk_slot_bytes(f), workspace_bytes);
+      return MMI_ERR_WORKSPACE;
+    }
+    p.sk_count = (int*)workspace;
+    p.sk_slots = (float*)((char*)workspace + slot_offset);
+    const dim3 grid(f.sk_grid), block(256);
+    if (g_gemm_prec == 1) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
+    if (g_gemm_prec == 2) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
+    if (g_gemm_prec == 3) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
+    if (uni) {
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
+    } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
+    MMI_CHECK_LAUNCH(who);
+    return MMI_OK;
+  }
+  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
+#define LAUNCH(BM_, BN_, VEC_)                                                                      \
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p)
+  if (vec && g_gemm_prec >= 1) {
+#define LAUNCH_B3(BM_, BN_)                                                                                          \
+  do {                                                                                                               \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1, EPI>), grid, block, 0, s, p); \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI>), grid, block, 0, s, p); \
+    else if (g_gemm_prec == 5) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 5, EPI>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI>), grid, block, 0, s, p);                  \
+  } while (0)
+    if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
+    else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
+    else LAUNCH_B3(64, 64);
+#undef LAUNCH_B3
+    MMI_CHECK_LAUNCH(who);
+    return MMI_OK;
+  }
+  if (!vec) {
+    if (EPI) {
+      mmi_set_error("%s: the fused Linear epilogues need channel counts and row strides that are multiples of 4", who);
+      return MMI_ERR_ARG;
+    }
+    if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
+    else LAUNCH(64, 64, false);
+  } else if (uni) {
+#define LAUNCH_UNI(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 0, EPI, true>), grid, block, 0, s, p)
+    if constexpr (DGRAD && !EPI) {
+      static const bool w41_off = getenv("MMIDET_DGRAD_W41") != nullptr && atoi(getenv("MMIDET_DGRAD_W41")) == 0;   // (A/B switch)
+      if (f.bm == 128 && f.bn == 64 && p.Ncol <= 32 && !w41_off) {
+        hipLaunchKernelGGL((igemm_kernel<128, 64, true, true, false, 0, false, true, true>), grid, block, 0, s, p);
+        MMI_CHECK_LAUNCH(who);
+        return MMI_OK;
+      }
+    }
+    if (f.bm == 128 && f.bn == 128) LAUNCH_UNI(128, 128);
+    else if (f.bm == 128 && f.bn == 64) LAUNCH_UNI(128, 64);
+    else LAUNCH_UNI(64, 64);
+#undef LAUNCH_UNI
+  } else if (f.bm == 128 && f.bn == 128) LAUNCH(128, 128, true);
+  else if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, true);
+  else LAUNCH(64, 64, true);
+#undef LAUNCH
+  MMI_CHECK_LAUNCH(who);
+  return MMI_OK;
+}
+
+// ---- bf16 storage: activations and activation gradients are bf16 in HBM, weights / weight gradients /
+// BatchNorm statistics fp32; one bf16 MFMA product per element pair with fp32 accumulation (igemm_kernel<..., PREC = 4>).
+// One workgroup per tile (no stream-K: these launches are HBM-bound, not wave-quantisation-bound).
+template <bool DGRAD, bool EPI>
+int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who) {
+  p.zero = zero_src();
+  if (p.zero == nullptr) {
+    mmi_set_error("%s: cannot resolve the zero-source symbol", who);
+    return MMI_ERR_LAUNCH;
+  }
+  p.mtiles = f.mtiles;
+  p.ntiles = f.ntiles;
+  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
+  if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  MMI_CHECK_LAUNCH(who);
+  return MMI_OK;
+}
+
+}  // namespace mmi_ig
