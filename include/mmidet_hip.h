@@ -196,6 +196,53 @@ int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const fl
                    float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C,
                    int act, int frozen, void* stream);
 
+/* ---- channel maps and twin launches ---------------------------------------------------------------------------------------
+ * The reference walks its RGB and IR backbones as two sequences of identical layers (models/yolo_test.py:162-273; the default
+ * YAML's rows 0-2 / 3-5, 9-10 / 11-12, ...).  Here the two lanes' activations are the two channel halves of ONE NHWC buffer
+ * (lane stride = C, row stride = 2C) and a "twin" entry point carries both lanes' GEMMs in one launch (gridDim.z = 2): twice the
+ * tiles per launch, half the launches, no second stream racing for the CUs; everything per-channel around the GEMM (BatchNorm,
+ * activation, residual, pooling) runs once over the 2C-channel buffer.
+ *
+ * mmi_bn_map describes such a buffer to the BatchNorm kernels.  Parameter blocks: channel c takes gamma/beta (and writes
+ * dgamma/dbeta) of block c / blk, element c % blk -- one block for a plain layer, two for C3's merged cv1|cv2 conv, two for a twin
+ * layer, four for a twin cv1|cv2.  Scatter: with lane = c / period and r = c % period, channel c of the activated output (of the
+ * incoming gradient, in backward) lives at  t0 + lane * ls0 + r  when r < split, else at  t1 + lane * ls1 + (r - split).  Plain:
+ * period = split = C.  All of blk, period, split, ls0, ls1 multiples of 4 keeps the 16-byte lane accesses. */
+typedef struct {
+  const float* gamma[4];
+  const float* beta[4];
+  float* dgamma[4];               /* backward only */
+  float* dbeta[4];
+  int32_t nblk, blk;
+  int32_t period, split, ls0, ls1;
+} mmi_bn_map;
+int mmi_bn_act_fwd_map(const float* y, int ldy, const float* mean_invstd, const mmi_bn_map* map, const float* residual, int ldr,
+                       float* out, int ldo, float* out1, int ldo1, int64_t rows, int C, int act, void* stream);
+int mmi_bn_act_bwd_map(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, const float* mean_invstd,
+                       const mmi_bn_map* map, void* workspace, size_t workspace_bytes, float* dy, int lddy, int64_t rows, int C,
+                       int act, int frozen, void* stream);
+/* Planner queries for a launch that carries `nprob` (1 or 2) problems of shape d: the tile plan looks at all the tiles of the
+ * launch, so row-block counts and workspaces differ from the single-problem answers.  Workspaces cover ALL problems
+ * (256-byte aligned, zero-filled when first handed over, self-cleaning). */
+int mmi_conv_fwd_row_blocks_n(const mmi_conv_desc* d, int nprob);
+size_t mmi_conv_fwd_workspace_n(const mmi_conv_desc* d, int nprob);
+size_t mmi_conv_dgrad_workspace_n(const mmi_conv_desc* d, int nprob);
+size_t mmi_conv_wgrad_workspace_n(const mmi_conv_desc* d, int nprob);
+/* Twin training-mode Conv: y[g] = conv(x[g], w[g]) for g = 0, 1 with the BatchNorm batch statistics of both finished in the
+ * launch (as mmi_conv_bn_fwd).  bn = array of two; problem g writes mean to bn[g].mean_invstd[0..Cout) and 1/std to
+ * bn[g].mean_invstd[mi_stride ..) -- pass mean_invstd = mi + g * Cout and mi_stride = 2 * Cout for one (2, 2*Cout) vector that
+ * the map kernels read.  stat_partials[g]: (row_blocks_n + 64) * 2 * Cout floats each. */
+int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, float* const* y, float* const* stat_partials,
+                     const mmi_bn_stats* bn, int mi_stride, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                     void* stream);
+/* dx[g] = conv_transpose(dy[g], w[g]) [+ skip[g]]; skip (row stride ldskip; may alias dx) only for 1x1 stride-1 layers, else NULL */
+int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                    void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+/* dw[g] = dy[g]^T x[g] (and dbias[g] = column sums of dy[g] when dbias != NULL); `table` as for mmi_conv_wgrad_tab (shapes only:
+ * one table serves both problems) or NULL */
+int mmi_conv_wgrad2(const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,
+                    size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream);
+
 /* ---- Contour Enhancement Module special forms (models/common.py:751-911) --------------------------------------------
  * The 3->24 and 24->3 convs of AdaptiveModule3 are served by mmi_conv_fwd/dgrad/wgrad themselves (direct VALU kernels,
  * selected by the descriptor).  The 24->24 EnhanceConv2d never runs as a convolution:
@@ -221,6 +268,8 @@ int mmi_u8_pair_to_nhwc(const uint8_t* in, float* rgb, float* ir, int N, int H, 
 /* Focus space-to-depth (models/common.py:708): in (N,H,W,C) -> out (N,H/2,W/2,4C), channel = q*C+c,
  * q: (dy,dx)=(0,0),(1,0),(0,1),(1,1).  inverse=1: in is a (N,H/2,W/2,4C) gradient, out the (N,H,W,C) gradient. */
 int mmi_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream);
+/* the same with a row stride on the depth-side tensor (a channel block of a wider buffer: the twin-lane Focus input) */
+int mmi_space_to_depth_ld(const float* in, float* out, int N, int H, int W, int C, int ldd, int inverse, void* stream);
 /* Detect view/permute (models/yolo_test.py:54-55): in (B,P=ny*nx,na*no) -> out (B,na,P,no); inverse=1 maps a
  * (B,na,P,no) gradient back to (B,P,na*no). */
 int mmi_head_permute(const float* in, float* out, int B, int na, int no, int P, int inverse, void* stream);

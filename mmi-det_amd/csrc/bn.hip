@@ -142,25 +142,42 @@ __device__ __forceinline__ void stv(float* p, const Vec<V>& r) {
 // Streaming kernels: when the grid stride is a multiple of the C/V column groups (FIXED; every power-of-two C of the
 // model), a thread keeps its column group, so the per-channel parameters are loaded once and no 64-bit division runs per
 // element; otherwise the general index arithmetic is used.
-// Output channels [0, split) go to out (row stride ldo), channels [split, C) to out1 (ldo1): C3's merged cv1|cv2 conv hands
-// its first half to the bottleneck chain and writes the second half straight into the concat buffer (split = C: one output).
+// Channel maps (mmi_bn_map, include/mmidet_hip.h).  The C channels of a conv output may belong to up to four BatchNorm
+// modules (parameter blocks of `blk` channels: C3's merged cv1|cv2 conv has two, the twin RGB|IR form of it four), and the
+// activated output may be scattered over two tensors: with lane = c / period and r = c % period, channel c goes to
+// t0 + lane * ls0 + r when r < split, else to t1 + lane * ls1 + (r - split).  A plain layer is period = split = C; C3's merged
+// conv hands its first half to the bottleneck chain and writes the second half straight into the concat buffer (split = C/2);
+// the twin forms repeat that per lane.  The backward reads the incoming gradient through the same map.
+__device__ __forceinline__ const float* sel4(const float* const (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+__device__ __forceinline__ float* sel4(float* const (&a)[4], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+struct ChanLoc {
+  bool hi;
+  int off;   // element offset inside t0 / t1 (row offset excluded)
+};
+__device__ __forceinline__ ChanLoc chan_loc(const mmi_bn_map& m, int c) {
+  const int lane = c / m.period, r = c - lane * m.period;
+  ChanLoc l;
+  l.hi = r >= m.split;
+  l.off = l.hi ? lane * m.ls1 + (r - m.split) : lane * m.ls0 + r;
+  return l;
+}
 template <typename T, int V, bool FIXED>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ mi,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ mi, mmi_bn_map mp,
                                   const T* __restrict__ res, int ldr, T* __restrict__ out, int ldo,
-                                  T* __restrict__ out1, int ldo1, int split, int64_t rows, int C, int act) {
+                                  T* __restrict__ out1, int ldo1, int64_t rows, int C, int act) {
   const int cv = C / V;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (FIXED) {
     const int64_t r0 = e0 / cv, dr = stride / cv;
     const int c = (int)(e0 - r0 * cv) * V;
-    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
+    const int pb = c / mp.blk, pc = c - pb * mp.blk;
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(sel4(mp.gamma, pb) + pc), b = ldv<V>(sel4(mp.beta, pb) + pc);
     const T* py = y + r0 * ldy + c;
     const T* pr = res != nullptr ? res + r0 * ldr + c : nullptr;
-    const bool hi = c >= split;
-    const int ldo_ = hi ? ldo1 : ldo;
-    T* po = (hi ? out1 + (c - split) : out + c) + r0 * ldo_;
+    const ChanLoc loc = chan_loc(mp, c);
+    const int ldo_ = loc.hi ? ldo1 : ldo;
+    T* po = (loc.hi ? out1 : out) + loc.off + r0 * ldo_;
     const int64_t sy = dr * ldy, sr = dr * ldr, so = dr * ldo_;
 #pragma unroll 2
     for (int64_t r = r0; r < rows; r += dr, py += sy, po += so) {
@@ -182,8 +199,9 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float*
   for (int64_t e = e0; e < total; e += stride) {
     const int64_t r = e / cv;
     const int c = (int)(e - r * cv) * V;
-    const Vec<V> yy = ldv<V>(y + r * ldy + c), m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c),
-                 b = ldv<V>(beta + c);
+    const int pb = c / mp.blk, pc = c - pb * mp.blk;
+    const Vec<V> yy = ldv<V>(y + r * ldy + c), m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(sel4(mp.gamma, pb) + pc),
+                 b = ldv<V>(sel4(mp.beta, pb) + pc);
     Vec<V> o;
 #pragma unroll
     for (int k = 0; k < V; ++k) o.v[k] = act_fwd((yy.v[k] - m.v[k]) * is.v[k] * g.v[k] + b.v[k], act);
@@ -192,25 +210,19 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float*
 #pragma unroll
       for (int k = 0; k < V; ++k) o.v[k] += rr.v[k];
     }
-    stv<V>(c >= split ? out1 + r * ldo1 + (c - split) : out + r * ldo + c, o);
+    const ChanLoc loc = chan_loc(mp, c);
+    stv<V>(loc.hi ? out1 + r * ldo1 + loc.off : out + r * ldo + loc.off, o);
   }
 }
 
 // backward pass 1: block = (64-channel group, rows part); threads = (64/V channel lanes) x row lanes.  dout may come in two
 // tensors split at channel `split` (see bn_act_fwd_kernel).  With fold.cnt != null the workgroup that arrives last
 // (stat_arrive, common.h) also produces dbeta / dgamma, so the pass needs no "finalize" launch behind it.
-struct BnSplitOut {
-  float* dgamma0;
-  float* dbeta0;
-  float* dgamma1;
-  float* dbeta1;
-};
 template <typename T, int V>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
-                                     const T* __restrict__ dout1, int ldd1, int split,
-                                     const float* __restrict__ mi, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ partials, int64_t rows, int C,
-                                     int act, int64_t rows_per_part, StatFold fold, BnSplitOut o) {
+                                     const T* __restrict__ dout1, int ldd1, const float* __restrict__ mi, mmi_bn_map mp,
+                                     float* __restrict__ partials, int64_t rows, int C,
+                                     int act, int64_t rows_per_part, StatFold fold) {
   constexpr int CL = 64 / V, RL = 256 / CL;
   __shared__ float red[2][RL][64];
   __shared__ double redd[512];
@@ -223,10 +235,11 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* 
 #pragma unroll
   for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
   if (c < C) {
-    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c);
-    const bool hi = c >= split;
-    const T* pd = hi ? dout1 + (c - split) : dout + c;
-    const int ldd_ = hi ? ldd1 : ldd;
+    const int pb = c / mp.blk, pc = c - pb * mp.blk;
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(sel4(mp.gamma, pb) + pc), b = ldv<V>(sel4(mp.beta, pb) + pc);
+    const ChanLoc loc = chan_loc(mp, c);
+    const T* pd = (loc.hi ? dout1 : dout) + loc.off;
+    const int ldd_ = loc.hi ? ldd1 : ldd;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(pd + r * ldd_);
 #pragma unroll
@@ -257,9 +270,9 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* 
   if (!stat_arrive<64>(fold, blockIdx.y, blockIdx.x, blockIdx.x * 64, redd, &flag, t1, t2)) return;
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x < 64 && col < C) {
-    const bool hi = col >= split;
-    (hi ? o.dbeta1 + (col - split) : o.dbeta0 + col)[0] = (float)t1;
-    (hi ? o.dgamma1 + (col - split) : o.dgamma0 + col)[0] = (float)t2;
+    const int pb = col / mp.blk, pc = col - pb * mp.blk;
+    sel4(mp.dbeta, pb)[pc] = (float)t1;
+    sel4(mp.dgamma, pb)[pc] = (float)t2;
   }
 }
 
@@ -331,10 +344,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int n
 
 template <typename T, int V, bool FIXED>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dout, int ldd,
-                                    const T* __restrict__ dout1, int ldd1, int split,
-                                    const float* __restrict__ mi, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, BnSplitOut gs, T* __restrict__ dy, int lddy, int64_t rows, int C,
-                                    int act, int frozen) {
+                                    const T* __restrict__ dout1, int ldd1, const float* __restrict__ mi, mmi_bn_map mp,
+                                    T* __restrict__ dy, int lddy, int64_t rows, int C, int act, int frozen) {
   const int cv = C / V;
   const float inv_rows = 1.0f / (float)rows;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -342,12 +353,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* _
   if (FIXED) {
     const int64_t r0 = e0 / cv, dr = stride / cv;
     const int c = (int)(e0 - r0 * cv) * V;
-    const bool hi = c >= split;
-    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
-                 dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
-    const int ldd_ = hi ? ldd1 : ldd;
+    const int pb = c / mp.blk, pc = c - pb * mp.blk;
+    const Vec<V> m = ldv<V>(mi + c), is = ldv<V>(mi + C + c), g = ldv<V>(sel4(mp.gamma, pb) + pc), b = ldv<V>(sel4(mp.beta, pb) + pc),
+                 dg = ldv<V>(sel4(mp.dgamma, pb) + pc), db = ldv<V>(sel4(mp.dbeta, pb) + pc);
+    const ChanLoc loc = chan_loc(mp, c);
+    const int ldd_ = loc.hi ? ldd1 : ldd;
     const T* py = y + r0 * ldy + c;
-    const T* pd = (hi ? dout1 + (c - split) : dout + c) + r0 * ldd_;
+    const T* pd = (loc.hi ? dout1 : dout) + loc.off + r0 * ldd_;
     T* po = dy + r0 * lddy + c;
     const int64_t sy = dr * ldy, sd = dr * ldd_, so = dr * lddy;
 #pragma unroll 2
@@ -369,10 +381,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* _
   for (int64_t e = e0; e < total; e += stride) {
     const int64_t r = e / cv;
     const int c = (int)(e - r * cv) * V;
-    const bool hi = c >= split;
-    const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(hi ? dout1 + r * ldd1 + (c - split) : dout + r * ldd + c), m = ldv<V>(mi + c),
-                 is = ldv<V>(mi + C + c), g = ldv<V>(gamma + c), b = ldv<V>(beta + c),
-                 dg = ldv<V>(hi ? gs.dgamma1 + (c - split) : gs.dgamma0 + c), db = ldv<V>(hi ? gs.dbeta1 + (c - split) : gs.dbeta0 + c);
+    const int pb = c / mp.blk, pc = c - pb * mp.blk;
+    const ChanLoc loc = chan_loc(mp, c);
+    const Vec<V> yy = ldv<V>(y + r * ldy + c), dd = ldv<V>(loc.hi ? dout1 + r * ldd1 + loc.off : dout + r * ldd + loc.off), m = ldv<V>(mi + c),
+                 is = ldv<V>(mi + C + c), g = ldv<V>(sel4(mp.gamma, pb) + pc), b = ldv<V>(sel4(mp.beta, pb) + pc),
+                 dg = ldv<V>(sel4(mp.dgamma, pb) + pc), db = ldv<V>(sel4(mp.dbeta, pb) + pc);
     Vec<V> o;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -468,21 +481,54 @@ extern "C" int mmi_bn_eval_stats(const float* running_mean, const float* running
 }
 
 namespace {
+// map of the entry points that take plain parameter vectors: one block, or two blocks split at `split` (gradients in two tensors)
+mmi_bn_map plain_map(const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dgamma1, float* dbeta1, int split, int C) {
+  mmi_bn_map m{};
+  m.period = C; m.split = split; m.ls0 = 0; m.ls1 = 0;
+  m.blk = split < C ? split : C;
+  m.nblk = cdiv(C, m.blk);
+  for (int k = 0; k < 4 && k < m.nblk; ++k) {
+    m.gamma[k] = gamma + (size_t)k * m.blk;
+    m.beta[k] = beta + (size_t)k * m.blk;
+    m.dgamma[k] = k == 0 ? dgamma : (dgamma1 ? dgamma1 + (size_t)(k - 1) * m.blk : nullptr);
+    m.dbeta[k] = k == 0 ? dbeta : (dbeta1 ? dbeta1 + (size_t)(k - 1) * m.blk : nullptr);
+  }
+  return m;
+}
+int check_map(const mmi_bn_map& m, int C, bool backward, const char* who) {
+  MMI_CHECK_ARG(m.nblk >= 1 && m.nblk <= 4 && m.blk > 0 && (int64_t)m.nblk * m.blk >= C, "%s: parameter blocks (%d x %d) do not cover %d channels", who, m.nblk, m.blk, C);
+  for (int k = 0; k < m.nblk; ++k)
+    MMI_CHECK_ARG(m.gamma[k] && m.beta[k] && (!backward || (m.dgamma[k] && m.dbeta[k])), "%s: null parameter pointer in block %d", who, k);
+  MMI_CHECK_ARG(m.period > 0 && m.split > 0 && m.split <= m.period && C % m.period == 0, "%s: bad channel map (period %d, split %d, C %d)", who, m.period, m.split, C);
+  return MMI_OK;
+}
+bool map_vec_ok(const mmi_bn_map& m, bool backward) {
+  if (m.blk % 4 || m.period % 4 || m.split % 4 || m.ls0 % 4 || m.ls1 % 4) return false;
+  for (int k = 0; k < m.nblk; ++k) {
+    if (((uintptr_t)m.gamma[k] | (uintptr_t)m.beta[k]) & 15) return false;
+    if (backward && (((uintptr_t)m.dgamma[k] | (uintptr_t)m.dbeta[k]) & 15)) return false;
+  }
+  return true;
+}
+bool map_two(const mmi_bn_map& m) { return m.split < m.period; }
+
 template <typename T>
-int bn_act_fwd_impl(const T* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta, const T* residual, int ldr,
-                    T* out, int ldo, T* out1, int ldo1, int split, int64_t rows, int C, int act, void* stream) {
-  MMI_CHECK_ARG(y && mean_invstd && gamma && beta && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
-  MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (out1 && split % 4 == 0 && ldo1 >= C - split)), "mmi_bn_act_fwd: bad channel split");
-  MMI_CHECK_ARG(ldy >= C && ldo >= split && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
+int bn_act_fwd_impl(const T* y, int ldy, const float* mean_invstd, const mmi_bn_map& mp, const T* residual, int ldr,
+                    T* out, int ldo, T* out1, int ldo1, int64_t rows, int C, int act, void* stream) {
+  MMI_CHECK_ARG(y && mean_invstd && out && rows > 0 && C > 0, "mmi_bn_act_fwd: bad arguments");
+  if (int e = check_map(mp, C, false, "mmi_bn_act_fwd")) return e;
+  const bool two = map_two(mp);
+  MMI_CHECK_ARG(!two || out1 != nullptr, "mmi_bn_act_fwd: the channel map needs a second output");
+  MMI_CHECK_ARG(ldy >= C && (!residual || ldr >= C), "mmi_bn_act_fwd: row stride < C");
   hipStream_t s = (hipStream_t)stream;
   const uintptr_t am = 4 * sizeof(T) - 1;
-  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0, split < C ? ldo1 : 0}, {y, out, residual, split < C ? out1 : nullptr}, am) &&
-                   vec_ok(C, {}, {mean_invstd, gamma, beta});
+  const bool vec = vec_ok(C, {ldy, ldo, residual ? ldr : 0, two ? ldo1 : 0}, {y, out, residual, two ? out1 : nullptr}, am) &&
+                   vec_ok(C, {}, {mean_invstd}) && map_vec_ok(mp, false);
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_FWD(V_, F_) \
-  hipLaunchKernelGGL((bn_act_fwd_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, gamma, beta, residual, \
-                     ldr, out, ldo, out1, ldo1, split, rows, C, act)
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, mean_invstd, mp, residual, \
+                     ldr, out, ldo, out1, ldo1, rows, C, act)
   if (vec && fixed) LAUNCH_FWD(4, true);
   else if (vec) LAUNCH_FWD(4, false);
   else if (fixed) LAUNCH_FWD(1, true);
@@ -491,25 +537,44 @@ int bn_act_fwd_impl(const T* y, int ldy, const float* mean_invstd, const float* 
   MMI_CHECK_LAUNCH("mmi_bn_act_fwd");
   return MMI_OK;
 }
+int check_split(int split, int C, const void* second, int ld1, const char* who) {
+  MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (second && split % 4 == 0 && ld1 >= C - split)), "%s: bad channel split", who);
+  return MMI_OK;
+}
 }  // namespace
 
 extern "C" int mmi_bn_act_fwd_split(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
                                     const float* residual, int ldr, float* out, int ldo, float* out1, int ldo1, int split,
                                     int64_t rows, int C, int act, void* stream) {
-  return bn_act_fwd_impl<float>(y, ldy, mean_invstd, gamma, beta, residual, ldr, out, ldo, out1, ldo1, split, rows, C, act, stream);
+  MMI_CHECK_ARG(gamma && beta && ldo >= split, "mmi_bn_act_fwd: bad arguments");
+  if (int e = check_split(split, C, out1, ldo1, "mmi_bn_act_fwd")) return e;
+  mmi_bn_map m = plain_map(gamma, beta, nullptr, nullptr, nullptr, nullptr, C, C);
+  m.split = split;
+  return bn_act_fwd_impl<float>(y, ldy, mean_invstd, m, residual, ldr, out, ldo, out1, ldo1, rows, C, act, stream);
 }
 
 extern "C" int mmi_bn_act_fwd_split_bf16(const void* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
                                          const void* residual, int ldr, void* out, int ldo, void* out1, int ldo1, int split,
                                          int64_t rows, int C, int act, void* stream) {
-  return bn_act_fwd_impl<__bf16>((const __bf16*)y, ldy, mean_invstd, gamma, beta, (const __bf16*)residual, ldr, (__bf16*)out, ldo,
-                                 (__bf16*)out1, ldo1, split, rows, C, act, stream);
+  MMI_CHECK_ARG(gamma && beta && ldo >= split, "mmi_bn_act_fwd_bf16: bad arguments");
+  if (int e = check_split(split, C, out1, ldo1, "mmi_bn_act_fwd_bf16")) return e;
+  mmi_bn_map m = plain_map(gamma, beta, nullptr, nullptr, nullptr, nullptr, C, C);
+  m.split = split;
+  return bn_act_fwd_impl<__bf16>((const __bf16*)y, ldy, mean_invstd, m, (const __bf16*)residual, ldr, (__bf16*)out, ldo,
+                                 (__bf16*)out1, ldo1, rows, C, act, stream);
 }
 
 extern "C" int mmi_bn_act_fwd(const float* y, int ldy, const float* mean_invstd, const float* gamma, const float* beta,
                               const float* residual, int ldr, float* out, int ldo, int64_t rows, int C, int act,
                               void* stream) {
   return mmi_bn_act_fwd_split(y, ldy, mean_invstd, gamma, beta, residual, ldr, out, ldo, nullptr, 0, C, rows, C, act, stream);
+}
+
+// the channel-map form (see bn_act_fwd_kernel): up to four parameter blocks, output scattered per lane over out / out1
+extern "C" int mmi_bn_act_fwd_map(const float* y, int ldy, const float* mean_invstd, const mmi_bn_map* map, const float* residual,
+                                  int ldr, float* out, int ldo, float* out1, int ldo1, int64_t rows, int C, int act, void* stream) {
+  MMI_CHECK_ARG(map != nullptr, "mmi_bn_act_fwd_map: null map");
+  return bn_act_fwd_impl<float>(y, ldy, mean_invstd, *map, residual, ldr, out, ldo, out1, ldo1, rows, C, act, stream);
 }
 
 extern "C" int mmi_bn_bwd_parts(int64_t rows) {
@@ -526,33 +591,32 @@ extern "C" int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout,
   const dim3 grid(cdiv(C, 64), nparts);
   hipStream_t s = (hipStream_t)stream;
   const StatFold nofold{};
-  const BnSplitOut noout{};
+  const mmi_bn_map mp = plain_map(gamma, beta, nullptr, nullptr, nullptr, nullptr, C, C);
   if (C <= 8)
     hipLaunchKernelGGL(bn_bwd_reduce_narrow_kernel, dim3(1, nparts), dim3(256), 0, s, y, ldy, dout, ldd, mean_invstd, gamma,
                        beta, partials, rows, C, act, rpp);
   else if (vec_ok(C, {ldy, ldd}, {y, dout, mean_invstd, gamma, beta}))
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
-                       beta, partials, rows, C, act, rpp, nofold, noout);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, mean_invstd, mp,
+                       partials, rows, C, act, rpp, nofold);
   else
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, C, mean_invstd, gamma,
-                       beta, partials, rows, C, act, rpp, nofold, noout);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, (const float*)nullptr, 0, mean_invstd, mp,
+                       partials, rows, C, act, rpp, nofold);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_reduce");
   return MMI_OK;
 }
 
 namespace {
 template <typename T>
-int launch_apply(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split,
-                 const float* mean_invstd, const float* gamma, const float* beta, const BnSplitOut& gs, T* dy, int lddy,
-                 int64_t rows, int C, int act, int frozen, hipStream_t s) {
-  const bool two = split < C;
-  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0, two ? split : 0}, {y, dout, dy, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) &&
-                   vec_ok(C, {}, {mean_invstd, gamma, beta, gs.dgamma0, gs.dbeta0, two ? gs.dgamma1 : nullptr, two ? gs.dbeta1 : nullptr});
+int launch_apply(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, const float* mean_invstd, const mmi_bn_map& mp,
+                 T* dy, int lddy, int64_t rows, int C, int act, int frozen, hipStream_t s) {
+  const bool two = map_two(mp);
+  const bool vec = vec_ok(C, {ldy, ldd, lddy, two ? ldd1 : 0}, {y, dout, dy, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) &&
+                   vec_ok(C, {}, {mean_invstd}) && map_vec_ok(mp, true);
   bool fixed;
   const int blocks = ew_grid(rows, vec ? C / 4 : C, &fixed);
 #define LAUNCH_APPLY(V_, F_) \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, \
-                     gamma, beta, gs, dy, lddy, rows, C, act, frozen)
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V_, F_>), dim3(blocks), dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, mean_invstd, mp, \
+                     dy, lddy, rows, C, act, frozen)
   if (vec && fixed) LAUNCH_APPLY(4, true);
   else if (vec) LAUNCH_APPLY(4, false);
   else if (fixed) LAUNCH_APPLY(1, true);
@@ -572,8 +636,8 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
-  const BnSplitOut gs{dgamma, dbeta, nullptr, nullptr};
-  return launch_apply<float>(y, ldy, dout, ldd, nullptr, 0, C, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  const mmi_bn_map mp = plain_map(gamma, beta, dgamma, dbeta, nullptr, nullptr, C, C);
+  return launch_apply<float>(y, ldy, dout, ldd, nullptr, 0, mean_invstd, mp, dy, lddy, rows, C, act, frozen, s);
 }
 
 // One-call BatchNorm(+activation) backward: reduce (whose last-arriving workgroups write dgamma / dbeta) + apply = two
@@ -587,40 +651,39 @@ extern "C" size_t mmi_bn_act_bwd_workspace(int64_t rows, int C) {
 
 namespace {
 template <typename T>
-int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, int split, const float* mean_invstd,
-                    const float* gamma, const float* beta, void* workspace, size_t workspace_bytes, T* dy, int lddy, float* dgamma,
-                    float* dbeta, float* dgamma1, float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
-  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && workspace && dy && dgamma && dbeta && rows > 0 && C > 0,
-                "mmi_bn_act_bwd: bad arguments");
-  MMI_CHECK_ARG(split > 0 && split <= C && (split == C || (dout1 && dgamma1 && dbeta1 && split % 4 == 0 && ldd1 >= C - split && C > 8)),
-                "mmi_bn_act_bwd: bad channel split");
+int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, const float* mean_invstd,
+                    const mmi_bn_map& mp, void* workspace, size_t workspace_bytes, T* dy, int lddy, int64_t rows, int C, int act,
+                    int frozen, void* stream) {
+  MMI_CHECK_ARG(y && dout && mean_invstd && workspace && dy && rows > 0 && C > 0, "mmi_bn_act_bwd: bad arguments");
+  if (int e = check_map(mp, C, true, "mmi_bn_act_bwd")) return e;
+  const bool two = map_two(mp);
+  MMI_CHECK_ARG(!two || (dout1 != nullptr && C > 8), "mmi_bn_act_bwd: the channel map needs a second gradient tensor");
   MMI_CHECK_ARG(workspace_bytes >= mmi_bn_act_bwd_workspace(rows, C) && ((uintptr_t)workspace & 15) == 0, "mmi_bn_act_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int nparts = mmi_bn_bwd_parts(rows);
   const int64_t rpp = (rows + nparts - 1) / nparts;
   float* partials = (float*)((char*)workspace + (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int));
-  const BnSplitOut gs{dgamma, dbeta, dgamma1, dbeta1};
   const int nct = cdiv(C, 64), G = stat_group_size(nparts), ngroups = cdiv(nparts, G);
   static const bool fold_off = getenv("MMIDET_BN_FOLD") != nullptr && atoi(getenv("MMIDET_BN_FOLD")) == 0;  // (A/B switch)
   const bool is_f32 = sizeof(T) == 4;
-  if (is_f32 && split == C && (C <= 8 || fold_off || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS)) {  // the CEM's 3-channel map: one thread per row, separate fold
-    if (int e = mmi_bn_act_bwd_reduce((const float*)y, ldy, (const float*)dout, ldd, mean_invstd, gamma, beta, partials, rows, C, act, stream)) return e;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, dgamma, dbeta, 1);
+  const bool plain = mp.nblk == 1 && !two && mp.period == C;
+  if (is_f32 && plain && (C <= 8 || fold_off || ngroups * nct + nct > MMI_STAT_MAX_COUNTERS)) {  // the CEM's 3-channel map: one thread per row, separate fold
+    if (int e = mmi_bn_act_bwd_reduce((const float*)y, ldy, (const float*)dout, ldd, mean_invstd, mp.gamma[0], mp.beta[0], partials, rows, C, act, stream)) return e;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)partials, nparts, C, mp.dgamma[0], mp.dbeta[0], 1);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(finalize)");
   } else {
     MMI_CHECK_ARG(ngroups * nct + nct <= MMI_STAT_MAX_COUNTERS, "mmi_bn_act_bwd: too many column tiles");
     StatFold f{partials, partials + (size_t)nparts * 2 * C, (int*)workspace, nparts, C, nct, G};
     const dim3 grid(nct, nparts);
-    const bool two = split < C;
-    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) && vec_ok(C, {}, {mean_invstd, gamma, beta}))
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
-                         partials, rows, C, act, rpp, f, gs);
+    if (vec_ok(C, {ldy, ldd, two ? ldd1 : 0}, {y, dout, two ? dout1 : nullptr}, 4 * sizeof(T) - 1) && vec_ok(C, {}, {mean_invstd}) && map_vec_ok(mp, false))
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, mean_invstd, mp,
+                         partials, rows, C, act, rpp, f);
     else
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta,
-                         partials, rows, C, act, rpp, f, gs);
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, y, ldy, dout, ldd, dout1, ldd1, mean_invstd, mp,
+                         partials, rows, C, act, rpp, f);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(reduce)");
   }
-  return launch_apply<T>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, gs, dy, lddy, rows, C, act, frozen, s);
+  return launch_apply<T>(y, ldy, dout, ldd, dout1, ldd1, mean_invstd, mp, dy, lddy, rows, C, act, frozen, s);
 }
 }  // namespace
 
@@ -628,17 +691,32 @@ extern "C" int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ld
                               const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
                               size_t workspace_bytes, float* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
                               float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
-  return bn_act_bwd_impl<float>(y, ldy, dout, ldd, dout1, ldd1, split, mean_invstd, gamma, beta, workspace, workspace_bytes, dy, lddy,
-                                dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen, stream);
+  MMI_CHECK_ARG(gamma && beta && dgamma && dbeta, "mmi_bn_act_bwd: bad arguments");
+  if (int e = check_split(split, C, dout1, ldd1, "mmi_bn_act_bwd")) return e;
+  MMI_CHECK_ARG(split == C || (dgamma1 && dbeta1), "mmi_bn_act_bwd: bad channel split");
+  return bn_act_bwd_impl<float>(y, ldy, dout, ldd, dout1, ldd1, mean_invstd, plain_map(gamma, beta, dgamma, dbeta, dgamma1, dbeta1, split, C),
+                                workspace, workspace_bytes, dy, lddy, rows, C, act, frozen, stream);
 }
 
 extern "C" int mmi_bn_act_bwd_bf16(const void* y, int ldy, const void* dout, int ldd, const void* dout1, int ldd1, int split,
                                    const float* mean_invstd, const float* gamma, const float* beta, void* workspace,
                                    size_t workspace_bytes, void* dy, int lddy, float* dgamma, float* dbeta, float* dgamma1,
                                    float* dbeta1, int64_t rows, int C, int act, int frozen, void* stream) {
-  return bn_act_bwd_impl<__bf16>((const __bf16*)y, ldy, (const __bf16*)dout, ldd, (const __bf16*)dout1, ldd1, split, mean_invstd, gamma,
-                                 beta, workspace, workspace_bytes, (__bf16*)dy, lddy, dgamma, dbeta, dgamma1, dbeta1, rows, C, act, frozen,
-                                 stream);
+  MMI_CHECK_ARG(gamma && beta && dgamma && dbeta, "mmi_bn_act_bwd_bf16: bad arguments");
+  if (int e = check_split(split, C, dout1, ldd1, "mmi_bn_act_bwd_bf16")) return e;
+  MMI_CHECK_ARG(split == C || (dgamma1 && dbeta1), "mmi_bn_act_bwd_bf16: bad channel split");
+  return bn_act_bwd_impl<__bf16>((const __bf16*)y, ldy, (const __bf16*)dout, ldd, (const __bf16*)dout1, ldd1, mean_invstd,
+                                 plain_map(gamma, beta, dgamma, dbeta, dgamma1, dbeta1, split, C), workspace, workspace_bytes,
+                                 (__bf16*)dy, lddy, rows, C, act, frozen, stream);
+}
+
+// the channel-map form: gradients of up to four parameter blocks, incoming gradient gathered per lane from dout / dout1
+extern "C" int mmi_bn_act_bwd_map(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1,
+                                  const float* mean_invstd, const mmi_bn_map* map, void* workspace, size_t workspace_bytes, float* dy,
+                                  int lddy, int64_t rows, int C, int act, int frozen, void* stream) {
+  MMI_CHECK_ARG(map != nullptr, "mmi_bn_act_bwd_map: null map");
+  return bn_act_bwd_impl<float>(y, ldy, dout, ldd, dout1, ldd1, mean_invstd, *map, workspace, workspace_bytes, dy, lddy, rows, C, act,
+                                frozen, stream);
 }
 
 extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {

@@ -43,7 +43,8 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
 }
 
 // y(N,H/2,W/2,4C): channel q*C+c <- x(n, 2*oh+dy, 2*ow+dx, c), q = dy + 2*dx   (common.py:708 slice order)
-__global__ void s2d_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int inverse) {
+// (ldd: row stride of the depth-side (N,H/2,W/2,4C) tensor, which may be a channel block of a wider buffer)
+__global__ void s2d_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int ldd, int inverse) {
   const int Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Ho * Wo * 4 * C;
   GRID_STRIDE(e, total) {
@@ -56,8 +57,9 @@ __global__ void s2d_kernel(const float* __restrict__ in, float* __restrict__ out
     const int q = cc / C, c = cc - q * C;
     const int dy = q & 1, dx = q >> 1;
     const int64_t xi = (((int64_t)n * H + 2 * oh + dy) * W + 2 * ow + dx) * C + c;
-    if (inverse) out[xi] = in[e];  // in: (N,H/2,W/2,4C) gradient, out: (N,H,W,C) gradient
-    else out[e] = in[xi];
+    const int64_t di = (e / (4 * C)) * ldd + cc;
+    if (inverse) out[xi] = in[di];  // in: (N,H/2,W/2,4C) gradient, out: (N,H,W,C) gradient
+    else out[di] = in[xi];
   }
 }
 
@@ -354,12 +356,15 @@ extern "C" int mmi_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, i
   return MMI_OK;
 }
 
-extern "C" int mmi_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream) {
-  MMI_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "mmi_space_to_depth: bad arguments");
+extern "C" int mmi_space_to_depth_ld(const float* in, float* out, int N, int H, int W, int C, int ldd, int inverse, void* stream) {
+  MMI_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldd >= 4 * C, "mmi_space_to_depth: bad arguments");
   hipLaunchKernelGGL(s2d_kernel, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, out, N, H, W,
-                     C, inverse);
+                     C, ldd, inverse);
   MMI_CHECK_LAUNCH("mmi_space_to_depth");
   return MMI_OK;
+}
+extern "C" int mmi_space_to_depth(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream) {
+  return mmi_space_to_depth_ld(in, out, N, H, W, C, 4 * C, inverse, stream);
 }
 
 extern "C" int mmi_add(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t rows, int C,

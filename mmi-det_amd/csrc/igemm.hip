@@ -72,7 +72,8 @@ int check_desc(const mmi_conv_desc* d, const char* who) {
 using namespace mmi_ig;
 
 namespace {
-FwdPlan plan_tiles(int64_t M, int Ncol) {
+// nprob: problems of this shape that share the launch (twin launches: 2); the grid the rules below look at is theirs together
+FwdPlan plan_tiles(int64_t M, int Ncol, int nprob = 1) {
   FwdPlan f;
   if (g_tile_bm > 0) {
     f.bm = g_tile_bm;
@@ -85,8 +86,8 @@ FwdPlan plan_tiles(int64_t M, int Ncol) {
   f.bn = Ncol > 64 ? 128 : 64;
   f.bm = 128;
   // small problems: shrink the tile until there are >= 2 workgroups per CU (256 CUs)
-  if (f.bn == 128 && (int64_t)cdiv(M, 128) * cdiv(Ncol, 128) < 512) f.bn = 64;
-  if ((int64_t)cdiv(M, 128) * cdiv(Ncol, f.bn) < 512) f.bm = 64, f.bn = 64;
+  if (f.bn == 128 && (int64_t)cdiv(M, 128) * cdiv(Ncol, 128) * nprob < 512) f.bn = 64;
+  if ((int64_t)cdiv(M, 128) * cdiv(Ncol, f.bn) * nprob < 512) f.bm = 64, f.bn = 64;
   f.mtiles = cdiv(M, f.bm);
   f.ntiles = cdiv(Ncol, f.bn);
   f.sk_grid = 0;
@@ -99,8 +100,8 @@ FwdPlan plan_tiles(int64_t M, int Ncol) {
 //    fills the chip evenly (>= 93 % of the last "layer" of 256);
 //  * short K (1x1 convs, token projections; tools/sweep_tiles.py): one workgroup per tile, plan_tiles' shrink rule.
 template <bool DGRAD>
-FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
-  FwdPlan f = plan_tiles(M, Ncol);
+FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk, int nprob = 1) {
+  FwdPlan f = plan_tiles(M, Ncol, nprob);
   if (!vec && f.bn == 128) f.bn = 64, f.ntiles = cdiv(Ncol, 64);
   static const bool off = getenv("MMIDET_NO_STREAMK") != nullptr;
   const int nk = cdiv(Ktot, BK);
@@ -111,15 +112,22 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
   g.mtiles = cdiv(M, 128);
   g.ntiles = cdiv(Ncol, g.bn);
   g.sk_grid = 0;
-  const int64_t tiles = (int64_t)g.mtiles * g.ntiles;
+  const int64_t tiles1 = (int64_t)g.mtiles * g.ntiles, tiles = tiles1 * nprob;   // per problem, in the launch
   const int cus = device_cus();
   const int slots = g_sk_slots > 0 ? g_sk_slots : cus * sk_occupancy<DGRAD>(g.bn);
   const double layers = (double)tiles / cus, dp_eff = layers / ceil(layers);
-  const bool sk_ok = !off && g_sk_slots >= 0 && nk >= (g_sk_slots > 0 ? 2 : 16) && tiles <= SK_MAX_TILES &&
+  const bool sk_ok = !off && g_sk_slots >= 0 && nk >= (g_sk_slots > 0 ? 2 : 16) && tiles1 <= SK_MAX_TILES &&
                      tiles * nk >= (int64_t)(g_sk_slots > 0 ? 1 : 32) * slots && tiles * nk < (1LL << 31);
   if (sk_ok) {
     if (g_sk_slots == 0 && tiles >= slots && dp_eff >= 0.93) return g;  // already even
+    // every problem runs its own stream-K iteration space on an equal share of the resident slots (a multiple of 8, so that
+    // workgroup b of either problem lands on XCD b % 8: xcd_remap)
     g.sk_grid = slots;
+    if (nprob > 1) {
+      g.sk_grid = slots / nprob;
+      if (g_sk_slots == 0) g.sk_grid &= ~7;   // (a forced test grid keeps its size)
+      if (g.sk_grid < 1) g.sk_grid = 1;
+    }
     return g;
   }
   // short K on many rows (the 1x1 convs): with the uniform-tap loaders the 64x64 tile no longer pays more address
@@ -140,17 +148,17 @@ FwdPlan plan_igemm(int64_t M, int Ncol, int Ktot, bool vec, bool allow_sk) {
 }
 
 bool fwd_vec(const mmi_conv_desc* d) { return d->Cin % 4 == 0 && d->ldx % 4 == 0; }
-FwdPlan fwd_plan(const mmi_conv_desc* d) {
-  return plan_igemm<false>((int64_t)d->N * d->Ho * d->Wo, d->Cout, d->KH * d->KW * d->Cin, fwd_vec(d), true);
+FwdPlan fwd_plan(const mmi_conv_desc* d, int nprob = 1) {
+  return plan_igemm<false>((int64_t)d->N * d->Ho * d->Wo, d->Cout, d->KH * d->KW * d->Cin, fwd_vec(d), true, nprob);
 }
 bool dgrad_vec(const mmi_conv_desc* d) { return d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->Cin % 4 == 0; }
 bool dgrad_par(const mmi_conv_desc* d) { return dgrad_vec(d) && d->stride == 2 && d->KH == 3; }
-FwdPlan dgrad_plan(const mmi_conv_desc* d) {
+FwdPlan dgrad_plan(const mmi_conv_desc* d, int nprob = 1) {
   // parity mode: the grid is sized for the largest class (ceil(H/2) x ceil(W/2) pixels per image); it keeps the
   // data-parallel schedule (four K extents in one launch)
   const bool par = dgrad_par(d);
   const int64_t mrows = par ? (int64_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (int64_t)d->N * d->H * d->W;
-  return plan_igemm<true>(mrows, d->Cin, d->KH * d->KW * d->Cout, dgrad_vec(d), !par);
+  return plan_igemm<true>(mrows, d->Cin, d->KH * d->KW * d->Cout, dgrad_vec(d), !par, nprob);
 }
 
 }  // namespace
@@ -366,6 +374,129 @@ extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* 
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
   p.par = dgrad_par(d) ? 1 : 0;
   return launch_igemm<true, false>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- twin launches ----------------------------------------------------------------------------------------------------
+// The RGB and IR backbones of the two-stream model (models/yolo_test.py:162-273 of the reference walks them layer by layer) run
+// the same layer shapes on different weights.  A twin entry point carries both problems in ONE launch (blockIdx.z = problem):
+// twice the tiles per launch (wave quantisation, ramp and drain are paid once), half the launches, and no second HIP stream
+// racing for the same CUs.  The two problems' activations are usually the two channel halves of one NHWC buffer (row strides
+// ldx / ldy span both), so everything per-channel around the GEMM (BatchNorm, activation, pooling) runs once over the buffer.
+// Workspace of a twin launch: [header of problem 0 | header of problem 1 | body 0 | body 1].  The headers (arrival counters, kept
+// at zero between launches by the kernels themselves) sit at FIXED offsets whatever the shape, because launches of different
+// shapes share one buffer per stream: a counter block at a shape-dependent offset would be another shape's scratch.
+namespace {
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+size_t twin_body_bytes(const FwdPlan& f, int Ncol_for_bn) { return align256((Ncol_for_bn ? bn_l1_bytes(f, Ncol_for_bn) : 0) + sk_slot_bytes(f)); }
+char* twin_hdr(void* ws, int g) { return (char*)ws + (size_t)g * WS_HEADER_BYTES; }
+char* twin_body(void* ws, int g, size_t body) { return (char*)ws + 2 * WS_HEADER_BYTES + (size_t)g * body; }
+void fill_fwd(IgemmP& p, const float* x, const float* w, float* y, float* part, const mmi_conv_desc* d) {
+  p.A = x; p.B = w; p.C = y; p.bias = nullptr; p.stat_part = part;
+  p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
+}
+void fill_dgrad(IgemmP& p, const float* dy, const float* w, float* dx, const mmi_conv_desc* d) {
+  p.A = dy; p.B = w; p.C = dx;
+  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
+  p.par = dgrad_par(d) ? 1 : 0;
+}
+bool twin_shape_ok(const mmi_conv_desc* d) { return !mmi_smallconv_supported(d) && !mmi_smallconv_dgrad_supported(d); }
+}  // namespace
+
+extern "C" int mmi_conv_fwd_row_blocks_n(const mmi_conv_desc* d, int nprob) {
+  if (check_desc(d, "mmi_conv_fwd_row_blocks_n") != MMI_OK || nprob < 1 || nprob > 2) return MMI_ERR_ARG;
+  return fwd_plan(d, nprob).mtiles;
+}
+
+extern "C" size_t mmi_conv_fwd_workspace_n(const mmi_conv_desc* d, int nprob) {
+  if (check_desc(d, "mmi_conv_fwd_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || !twin_shape_ok(d)) return 0;
+  if (nprob == 1) return fwd_workspace_bytes(fwd_plan(d, 1), d->Cout);
+  return 2 * WS_HEADER_BYTES + 2 * twin_body_bytes(fwd_plan(d, 2), d->Cout);
+}
+
+extern "C" size_t mmi_conv_dgrad_workspace_n(const mmi_conv_desc* d, int nprob) {
+  if (check_desc(d, "mmi_conv_dgrad_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || !twin_shape_ok(d)) return 0;
+  if (nprob == 1) return sk_workspace_bytes(dgrad_plan(d, 1));
+  const FwdPlan f = dgrad_plan(d, 2);
+  return f.sk_grid > 0 ? 2 * WS_HEADER_BYTES + 2 * twin_body_bytes(f, 0) : 0;
+}
+
+extern "C" int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, float* const* y, float* const* stat_partials,
+                                const mmi_bn_stats* bn, int mi_stride, void* workspace, size_t workspace_bytes,
+                                const mmi_conv_desc* d, void* stream) {
+  const char* who = "mmi_conv_bn_fwd2";
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(x && w && y && stat_partials && bn, "%s: null argument arrays", who);
+  MMI_CHECK_ARG(twin_shape_ok(d), "%s: the CEM's direct convolutions have no twin form", who);
+  const bool vec = fwd_vec(d);
+  const FwdPlan f = fwd_plan(d, 2);
+  MMI_CHECK_ARG(bn_fold_fits(f), "%s: statistics row list too long for the in-launch fold", who);
+  MMI_CHECK_ARG(mi_stride >= d->Cout, "%s: mi_stride %d < Cout", who, mi_stride);
+  const size_t body = twin_body_bytes(f, d->Cout), need = 2 * WS_HEADER_BYTES + 2 * body;
+  if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
+    mmi_set_error("%s: needs a 256-byte aligned zero-initialised workspace of %zu bytes (got %zu)", who, need, workspace_bytes);
+    return MMI_ERR_WORKSPACE;
+  }
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  IgemmP p[2];
+  for (int g = 0; g < 2; ++g) {
+    MMI_CHECK_ARG(x[g] && w[g] && y[g] && stat_partials[g] && bn[g].mean_invstd, "%s: null pointer (problem %d)", who, g);
+    MMI_CHECK_ARG(!vec || (((uintptr_t)x[g] | (uintptr_t)w[g]) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    MMI_CHECK_ARG((bn[g].running_mean == nullptr) == (bn[g].running_var == nullptr), "%s: running stats must come in pairs", who);
+    MMI_CHECK_ARG(bn[g].num_batches_tracked2 == nullptr || bn[g].num_batches_tracked2 == bn[g].num_batches_tracked + 1,
+                  "%s: the two num_batches_tracked counters of a problem must be adjacent", who);
+    p[g] = IgemmP{};
+    fill_fwd(p[g], x[g], w[g], y[g], stat_partials[g], d);
+    p[g].sk_count = (int*)twin_hdr(workspace, g);
+    p[g].sk_slots = (float*)(twin_body(workspace, g, body) + bn_l1_bytes(f, d->Cout));
+    p[g].bn_fold = StatFold{stat_partials[g], (float*)twin_body(workspace, g, body), (int*)(twin_hdr(workspace, g) + SK_COUNTER_BYTES), f.mtiles,
+                            d->Cout, f.ntiles, stat_group_size(f.mtiles)};
+    p[g].bn_mi = bn[g].mean_invstd; p[g].mi_stride = mi_stride;
+    p[g].bn_rmean = bn[g].running_mean; p[g].bn_rvar = bn[g].running_var;
+    p[g].bn_nbt = bn[g].num_batches_tracked;
+    p[g].bn_nnbt = bn[g].num_batches_tracked == nullptr ? 0 : (bn[g].num_batches_tracked2 != nullptr ? 2 : 1);
+    p[g].bn_eps = bn[g].eps; p[g].bn_momentum = bn[g].momentum;
+    p[g].bn_inv_rows = 1.0 / (double)rows; p[g].bn_unbias = rows > 1 ? (double)rows / (double)(rows - 1) : 1.0;
+  }
+  return launch_igemm<false, false>(p[0], f, vec, workspace, workspace_bytes, (hipStream_t)stream, 0, &p[1]);
+}
+
+// dx[g] = conv_transpose(dy[g], w[g]) [+ skip[g]]; skip (row stride ldskip) only for 1x1 stride-1 layers (GEMM epilogue), else NULL
+extern "C" int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                               void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  const char* who = "mmi_conv_dgrad2";
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(dy && w && dx, "%s: null argument arrays", who);
+  MMI_CHECK_ARG(twin_shape_ok(d), "%s: the CEM's direct convolutions have no twin form", who);
+  const bool vec = dgrad_vec(d);
+  const bool acc = skip != nullptr && skip[0] != nullptr;
+  MMI_CHECK_ARG(!acc || (skip[1] != nullptr && vec && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && ldskip >= d->Cin && ldskip % 4 == 0),
+                "%s: the skip accumulation exists for vector-shaped 1x1 stride-1 layers (both problems)", who);
+  const FwdPlan f = dgrad_plan(d, 2);
+  const size_t body = twin_body_bytes(f, 0), need = f.sk_grid > 0 ? 2 * WS_HEADER_BYTES + 2 * body : 0;
+  if (need != 0 && (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & 255))) {
+    mmi_set_error("%s: needs a 256-byte aligned zero-initialised workspace of %zu bytes (got %zu)", who, need, workspace_bytes);
+    return MMI_ERR_WORKSPACE;
+  }
+  IgemmP p[2];
+  for (int g = 0; g < 2; ++g) {
+    MMI_CHECK_ARG(dy[g] && w[g] && dx[g], "%s: null pointer (problem %d)", who, g);
+    MMI_CHECK_ARG(!vec || (((uintptr_t)dy[g] | (uintptr_t)w[g]) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    p[g] = IgemmP{};
+    fill_dgrad(p[g], dy[g], w[g], dx[g], d);
+    if (need != 0) {
+      p[g].sk_count = (int*)twin_hdr(workspace, g);
+      p[g].sk_slots = (float*)twin_body(workspace, g, body);
+    }
+    if (acc) {
+      p[g].epi = MMI_EPI_ACCUMULATE; p[g].aux = skip[g]; p[g].ldaux = ldskip; p[g].inv_keep = 1.0f;
+    }
+  }
+  if (acc) return launch_igemm<true, true>(p[0], f, vec, workspace, workspace_bytes, (hipStream_t)stream, 0, &p[1]);
+  return launch_igemm<true, false>(p[0], f, vec, workspace, workspace_bytes, (hipStream_t)stream, 0, &p[1]);
 }
 
 namespace {

@@ -52,7 +52,8 @@ struct IgemmP {
   // rows (stat_arrive, common.h) and write mean / 1/sqrt(var + eps), the running statistics and num_batches_tracked, so no
   // "finalize" launch follows the convolution.  bn_mi == null: the partial rows are all there is (mmi_conv_fwd).
   StatFold bn_fold;
-  float* bn_mi;
+  float* bn_mi;   // mean at [col], 1/std at [mi_stride + col]
+  int mi_stride;  // Ncol, or the channel count of a wider mean_invstd vector this layer owns a column block of (twin launches)
   float* bn_rmean;
   float* bn_rvar;
   int64_t* bn_nbt;
@@ -85,7 +86,7 @@ struct WgradP {
 };
 
 struct FwdPlan {
-  int bm, bn, mtiles, ntiles;
+  int bm, bn, mtiles, ntiles;   // per problem
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile
 };
 struct WgPlan {
@@ -125,7 +126,7 @@ inline size_t fwd_workspace_bytes(const FwdPlan& f, int Ncol) { return WS_HEADER
 // kernel launchers: defined in igemm_launch.h, instantiated once per (DGRAD, EPI) in igemm_fwd*.hip / igemm_dgrad*.hip
 template <bool DGRAD, bool EPI>
 int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s,
-                 size_t slot_offset = WS_HEADER_BYTES);
+                 size_t slot_offset = WS_HEADER_BYTES, const IgemmP* twin = nullptr);   // twin != null: both problems carry their own sk_count / sk_slots
 template <bool DGRAD, bool EPI>
 int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who);
 template <bool DGRAD>

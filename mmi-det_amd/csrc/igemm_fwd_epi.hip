@@ -2,6 +2,6 @@
 #include "igemm_launch.h"
 
 namespace mmi_ig {
-template int launch_igemm<false, true>(const IgemmP&, const FwdPlan&, bool, void*, size_t, hipStream_t, size_t);
+template int launch_igemm<false, true>(const IgemmP&, const FwdPlan&, bool, void*, size_t, hipStream_t, size_t, const IgemmP*);
 template int launch_igemm_bf16<false, true>(IgemmP, const FwdPlan&, hipStream_t, const char*);
 }  // namespace mmi_ig

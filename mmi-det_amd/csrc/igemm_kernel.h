@@ -195,7 +195,10 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // tile width, and skip the 32-column blocks beyond the last output column -- in the 2 x 2 layout half of the waves would own
 // nothing but padding and leave their SIMDs' matrix pipes idle.
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP prob0, IgemmP prob1) {
+  // twin launches (two problems of one shape, e.g. the RGB and IR backbone layers of the two-stream model): blockIdx.z picks the
+  // problem; a scalar select of the kernel-argument block, nothing per lane
+  const IgemmP& p = blockIdx.z ? prob1 : prob0;
   static_assert(!W41 || (DGRAD && !SK && PREC == 0 && !EPI && BM == 128), "the stacked wave layout exists for the plain fp32 dgrad tiles");
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
               double var = s2 * p.bn_inv_rows - mean * mean;  // biased (normalisation) variance
               if (var < 0.0) var = 0.0;
               p.bn_mi[col] = (float)mean;
-              p.bn_mi[p.Ncol + col] = 1.0f / sqrtf((float)(var + (double)p.bn_eps));
+              p.bn_mi[p.mi_stride + col] = 1.0f / sqrtf((float)(var + (double)p.bn_eps));
               if (p.bn_rmean != nullptr) {
                 p.bn_rmean[col] = (float)((1.0 - p.bn_momentum) * (double)p.bn_rmean[col] + p.bn_momentum * mean);
                 p.bn_rvar[col] = (float)((1.0 - p.bn_momentum) * (double)p.bn_rvar[col] + p.bn_momentum * (var * p.bn_unbias));

@@ -29,7 +29,7 @@ int sk_occupancy(int bn) {
 
 template <bool DGRAD, bool EPI>
 int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s,
-                 size_t slot_offset) {
+                 size_t slot_offset, const IgemmP* twin) {
   const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
   IgemmP p = p0;
   p.zero = zero_src();
@@ -39,6 +39,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   }
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
+  if (p.mi_stride == 0) p.mi_stride = p.Ncol;
   // uniform-tap loaders (igemm_kernel<..., UNI>): whole slabs inside one tap, tap table in 32 bits, 31-bit byte offsets
   bool uni = false;
   if (vec && g_uniform_loaders && g_gemm_prec == 0 && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
@@ -54,51 +55,63 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       p.c_bytes = c_bytes < (1LL << 31) ? (uint32_t)c_bytes : 0u;
     }
   }
+  // twin launch: a second problem of the same shape (other operand pointers, its own workspace) on gridDim.z = 2
+  const int nz = twin != nullptr ? 2 : 1;
+  IgemmP q = twin != nullptr ? *twin : p;
+  if (q.mi_stride == 0) q.mi_stride = q.Ncol;
+  q.zero = p.zero; q.mtiles = p.mtiles; q.ntiles = p.ntiles; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.c_bytes = p.c_bytes;
   if (f.sk_grid > 0) {
-    if (workspace == nullptr || workspace_bytes < slot_offset + sk_slot_bytes(f) || ((uintptr_t)workspace & 15)) {
+    if (twin != nullptr) {   // (the caller laid out both problems' counters and slots: igemm.hip, "twin launches")
+      if (p.sk_count == nullptr || p.sk_slots == nullptr || q.sk_count == nullptr || q.sk_slots == nullptr) {
+        mmi_set_error("%s: a twin launch of a stream-K shape needs both problems' workspaces", who);
+        return MMI_ERR_WORKSPACE;
+      }
+    } else if (workspace == nullptr || workspace_bytes < slot_offset + sk_slot_bytes(f) || ((uintptr_t)workspace & 15)) {
       mmi_set_error("%s: this shape runs the stream-K schedule and needs a 16-byte aligned workspace of %zu bytes (got %zu)",
                     who, slot_offset + sk_slot_bytes(f), workspace_bytes);
       return MMI_ERR_WORKSPACE;
     }
-    p.sk_count = (int*)workspace;
-    p.sk_slots = (float*)((char*)workspace + slot_offset);
-    const dim3 grid(f.sk_grid), block(256);
+    if (twin == nullptr) {
+      p.sk_count = (int*)workspace;
+      p.sk_slots = (float*)((char*)workspace + slot_offset);
+    }
+    const dim3 grid(f.sk_grid, 1, nz), block(256);
     if (g_gemm_prec == 1) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p, q);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p, q);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
     if (g_gemm_prec == 2) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p, q);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p, q);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
     if (g_gemm_prec == 3) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p, q);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p, q);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
     }
     if (uni) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p);
-    } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p);
+      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p, q);
+      else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI, true>), grid, block, 0, s, p, q);
+    } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p, q);
+    else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 0, EPI>), grid, block, 0, s, p, q);
     MMI_CHECK_LAUNCH(who);
     return MMI_OK;
   }
-  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
+  const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1, nz), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
-  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p)
+  hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p, q)
   if (vec && g_gemm_prec >= 1) {
 #define LAUNCH_B3(BM_, BN_)                                                                                          \
   do {                                                                                                               \
-    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1, EPI>), grid, block, 0, s, p); \
-    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI>), grid, block, 0, s, p); \
-    else if (g_gemm_prec == 5) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 5, EPI>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI>), grid, block, 0, s, p);                  \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 1, EPI>), grid, block, 0, s, p, q); \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI>), grid, block, 0, s, p, q); \
+    else if (g_gemm_prec == 5) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 5, EPI>), grid, block, 0, s, p, q); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI>), grid, block, 0, s, p, q);                  \
   } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_B3(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_B3(128, 64);
@@ -115,11 +128,11 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     if (f.bm == 128 && f.bn == 64) LAUNCH(128, 64, false);
     else LAUNCH(64, 64, false);
   } else if (uni) {
-#define LAUNCH_UNI(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 0, EPI, true>), grid, block, 0, s, p)
+#define LAUNCH_UNI(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 0, EPI, true>), grid, block, 0, s, p, q)
     if constexpr (DGRAD && !EPI) {
       static const bool w41_off = getenv("MMIDET_DGRAD_W41") != nullptr && atoi(getenv("MMIDET_DGRAD_W41")) == 0;   // (A/B switch)
       if (f.bm == 128 && f.bn == 64 && p.Ncol <= 32 && !w41_off) {
-        hipLaunchKernelGGL((igemm_kernel<128, 64, true, true, false, 0, false, true, true>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((igemm_kernel<128, 64, true, true, false, 0, false, true, true>), grid, block, 0, s, p, q);
         MMI_CHECK_LAUNCH(who);
         return MMI_OK;
       }
@@ -148,10 +161,12 @@ int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who
   }
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
+  if (p.mi_stride == 0) p.mi_stride = p.Ncol;
+  const IgemmP& q = p;   // (single problem)
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
-  if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
-  else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p);
+  if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
+  else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
+  else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
   MMI_CHECK_LAUNCH(who);
   return MMI_OK;
 }

@@ -25,7 +25,8 @@ namespace {
 // a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
 // resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
 template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
-__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP prob0, WgradP prob1) {
+  const WgradP& p = blockIdx.z ? prob1 : prob0;   // twin launches: blockIdx.z = problem (see igemm_kernel)
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
@@ -535,8 +536,13 @@ __global__ void wgrad_table_kernel(uint2* __restrict__ tab, int Mpix, int total,
 
 // out = sum over splits of slabs[z]: 16-byte lanes, 4 independent loads in flight per thread (HBM-bound)
 // (elements [0, n1) go to out, the bias tail [n1, n) to out2)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, float* __restrict__ out2,
+// (blockIdx.y = 1: the twin problem's slabs and outputs)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs0, float* __restrict__ out0, float* __restrict__ out20,
+                                   const float* __restrict__ slabs1, float* __restrict__ out1, float* __restrict__ out21,
                                    int64_t n1, int64_t n, int64_t count, int splits) {
+  const float* __restrict__ slabs = blockIdx.y ? slabs1 : slabs0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  float* __restrict__ out2 = blockIdx.y ? out21 : out20;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= count) return;  // count = n (with the bias tail) or n1 (without); n is the slab stride
   if (i + 4 <= n1 && (n & 3) == 0) {
@@ -589,7 +595,9 @@ int wgrad_slots(int bm, int bn, bool vec) {
   return per_cu * device_cus();
 }
 
-WgPlan wgrad_plan(const mmi_conv_desc* d) {
+// nprob: problems of this shape sharing the launch (twin launches: 2): their tiles fill the chip together, so each needs
+// fewer splits -- longer K chunks per workgroup and half the slab traffic per problem
+WgPlan wgrad_plan(const mmi_conv_desc* d, int nprob = 1) {
   WgPlan g;
   const int Ntot = d->KH * d->KW * d->Cin;
   const int64_t Mpix = (int64_t)d->N * d->Ho * d->Wo;
@@ -603,7 +611,7 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   // Split K (pixels) so that tiles*splits fills whole waves of the resident workgroups of the variant (wgrad_slots): a grid of 1.5 waves
   // wastes a quarter of the chip.  Fewer splits win ties (less slab traffic).
   int max_splits = (int)((Mpix + 511) / 512);                       // >= 512 pixels (16 K-steps) per split
-  if (g.vec && (int64_t)tiles * max_splits < 256) {
+  if (g.vec && (int64_t)tiles * nprob * max_splits < 256) {
     // a launch-bound GEMM (the token projections: 2048 rows x 128..512 channels): 64x64 tiles and K chunks of 128 pixels
     // put ~10x more workgroups on the chip; the slab traffic is kept below 8 MB
     g.bm = g.bn = 64;
@@ -615,7 +623,7 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
     if (max_splits > by_bytes) max_splits = (int)by_bytes;
   }
   const int slots = wgrad_slots(g.bm, g.bn, g.vec);
-  int cap = tiles > 64 ? 16 : cdiv(2 * slots, tiles);
+  int cap = tiles * nprob > 64 ? 16 : cdiv(2 * slots, tiles * nprob);
   if (cap > max_splits) cap = max_splits;
   if (cap < 1) cap = 1;
   // Every split costs a slab of dw to write and to read back: a split count is charged `pen` of wave efficiency per split
@@ -624,9 +632,22 @@ WgPlan wgrad_plan(const mmi_conv_desc* d) {
   int splits = 1;
   double best = -1e9;
   for (int sp = 1; sp <= cap; ++sp) {
-    const int blocks = tiles * sp;
+    const int blocks = tiles * nprob * sp;
     const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots) - pen * sp;
     if (eff > best + 1e-9) best = eff, splits = sp;
+  }
+  if (nprob > 1) {
+    // Twin launches: every split is a slab to write and read back for BOTH problems, and two problems fill a wave of the chip
+    // with half the splits each -- take the fewest splits within 5 % of the best wave efficiency (3x3 128->128 @80x80: 42 splits
+    // of 74 K slabs per problem instead of 85 of 37; the single-problem rule above is unchanged)
+    for (int sp = 1; sp <= cap; ++sp) {
+      const int blocks = tiles * nprob * sp;
+      const double eff = (double)blocks / (double)(cdiv(blocks, slots) * slots) - pen * sp;
+      if (eff >= best - 0.05) {
+        splits = sp;
+        break;
+      }
+    }
   }
   // Short-K GEMMs (the token projections: 2048 rows, i.e. at most 64 K-steps): tools/sweep_wgrad.py,
   // profiles/r02_sweep_wgrad.txt.  What wins there is enough workgroups WITHOUT leaving the in-launch fold (<= 4 splits): the
@@ -729,9 +750,18 @@ extern "C" int mmi_conv_wgrad_table_build(void* table, const mmi_conv_desc* d, v
 }
 
 namespace {
-int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                    const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io = false);
+size_t align256w(size_t n) { return (n + 255) & ~(size_t)255; }
+size_t wgrad_ws_one(const mmi_conv_desc* d, const WgPlan& g) {   // bytes of ONE problem's workspace
+  const size_t generic = g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
+  return generic ? WG_COUNTER_BYTES + generic : 0;
 }
+int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,
+                 size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io = false);
+int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                    const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io = false) {
+  return conv_wgrad_n(1, &dy, &x, &dw, &dbias, workspace, workspace_bytes, table, d, stream, bf16_io);
+}
+}  // namespace
 extern "C" int mmi_conv_wgrad(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
                               size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
   return conv_wgrad_impl(dy, x, dw, dbias, workspace, workspace_bytes, nullptr, d, stream);
@@ -740,76 +770,107 @@ extern "C" int mmi_conv_wgrad_tab(const float* dy, const float* x, float* dw, fl
                                   size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream) {
   return conv_wgrad_impl(dy, x, dw, dbias, workspace, workspace_bytes, table, d, stream);
 }
+// twin form (see igemm.hip, "twin launches"): two problems of one shape in one launch; dbias may be NULL (or hold NULLs);
+// workspace = mmi_conv_wgrad_workspace_n(d, 2) bytes, 256-byte aligned; the pixel table (shapes only) serves both
+extern "C" size_t mmi_conv_wgrad_workspace_n(const mmi_conv_desc* d, int nprob) {
+  if (check_desc(d, "mmi_conv_wgrad_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || mmi_smallconv_supported(d)) return 0;
+  if (nprob == 1) return wgrad_ws_one(d, wgrad_plan(d, 1));
+  const size_t one = wgrad_ws_one(d, wgrad_plan(d, 2));
+  return one ? 2 * WG_COUNTER_BYTES + 2 * align256w(one - WG_COUNTER_BYTES) : 0;   // [counters 0 | counters 1 | slabs 0 | slabs 1]
+}
+extern "C" int mmi_conv_wgrad2(const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,
+                               size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream) {
+  MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad2: null argument arrays");
+  float* const nob[2] = {nullptr, nullptr};
+  return conv_wgrad_n(2, dy, x, dw, dbias != nullptr ? dbias : nob, workspace, workspace_bytes, table, d, stream);
+}
 
 namespace {
-int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                    const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io) {
+int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,
+                 size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io) {
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
-  MMI_CHECK_ARG(dy && x && dw, "mmi_conv_wgrad: null pointer");
-  if (mmi_smallconv_supported(d) && dbias == nullptr && !bf16_io) {
+  for (int q = 0; q < nprob; ++q) MMI_CHECK_ARG(dy[q] && x[q] && dw[q], "mmi_conv_wgrad: null pointer");
+  const bool want_bias = dbias[0] != nullptr;
+  if (nprob == 1 && mmi_smallconv_supported(d) && !want_bias && !bf16_io) {
     if (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d)) {
       mmi_set_error("mmi_conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, WG_COUNTER_BYTES + mmi_smallconv_wgrad_workspace(d));
       return MMI_ERR_WORKSPACE;
     }
-    return mmi_smallconv_wgrad(dy, x, dw, (char*)workspace + WG_COUNTER_BYTES, d, (hipStream_t)stream);   // (never the counter block)
+    return mmi_smallconv_wgrad(dy[0], x[0], dw[0], (char*)workspace + WG_COUNTER_BYTES, d, (hipStream_t)stream);   // (never the counter block)
   }
-  const WgPlan g = wgrad_plan(d);
+  MMI_CHECK_ARG(nprob == 1 || (!mmi_smallconv_supported(d) && !bf16_io), "mmi_conv_wgrad2: no twin form for this shape / storage type");
+  const WgPlan g = wgrad_plan(d, nprob);
   MMI_CHECK_ARG(!bf16_io || g.vec, "mmi_conv_wgrad_bf16: channel counts and row strides must be multiples of 4");
-  MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy | (uintptr_t)x) & (bf16_io ? 7 : 15)) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
   const int64_t wsize = (int64_t)d->Cout * d->KH * d->KW * d->Cin;
   const int64_t slab = wsize + d->Cout;  // weight gradient + bias-gradient tail
-  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < WG_COUNTER_BYTES + (size_t)g.splits * slab * sizeof(float) ||
-                       ((uintptr_t)workspace & 15))) {
-    mmi_set_error("mmi_conv_wgrad: workspace too small or misaligned (%zu < %zu)", workspace_bytes,
-                  WG_COUNTER_BYTES + (size_t)g.splits * slab * sizeof(float));
+  // one problem: [counters | slabs]; two: [counters 0 | counters 1 | slabs 0 | slabs 1] (the counter blocks at fixed offsets: they
+  // must never be another shape's scratch, see igemm.hip "twin launches")
+  const size_t one = wgrad_ws_one(d, g), slab_bytes = one ? align256w(one - WG_COUNTER_BYTES) : 0;
+  const size_t need = nprob > 1 ? (one ? 2 * WG_COUNTER_BYTES + 2 * slab_bytes : 0) : one;
+  if (g.splits > 1 && (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace & (nprob > 1 ? 255 : 15)))) {
+    mmi_set_error("mmi_conv_wgrad: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
     return MMI_ERR_WORKSPACE;
   }
-  float* slabs = g.splits > 1 ? (float*)((char*)workspace + WG_COUNTER_BYTES) : nullptr;
   static const bool fold_off = getenv("MMIDET_WGRAD_FOLD") != nullptr && atoi(getenv("MMIDET_WGRAD_FOLD")) == 0;  // (A/B switch)
   // The fold runs on ONE workgroup per tile, serially over the splits (a dependent round of loads per four of them), while
-  // the reduce kernel spreads the same reads over the whole chip: measured (profiles/r02_wgrad_fold_microbench.txt) the fold
-  // only wins up to a handful of splits, so long split lists keep the separate reduce launch.
-  // Measured twice (profiles/r02_wgrad_fold_microbench.txt: one workgroup walking all splits; profiles/r02_ab_wgrad_fold_tree.txt:
-  // the fan-in-4 tree of the kernel's epilogue): the in-launch fold wins up to FOUR splits (one level of the tree) and loses
-  // beyond -- every level is a dependent round of device-coherent loads of slabs written on other XCDs (~6 us), against one
-  // chip-wide reduce launch that streams them: 3x3 128->128@80x80 0.266 -> 0.351 ms, the step 123.2 -> 125.3 ms with the tree
-  // for every split count.  So longer split lists keep the separate reduce launch; MMIDET_WGRAD_FOLD_MAX (<= 256) moves the limit.
+  // the reduce kernel spreads the same reads over the whole chip: measured twice (profiles/r02_wgrad_fold_microbench.txt: one
+  // workgroup walking all splits; profiles/r02_ab_wgrad_fold_tree.txt: the fan-in-4 tree of the kernel's epilogue) the
+  // in-launch fold wins up to FOUR splits (one level of the tree) and loses beyond -- every level is a dependent round of
+  // device-coherent loads of slabs written on other XCDs (~6 us), against one chip-wide reduce launch that streams them:
+  // 3x3 128->128@80x80 0.266 -> 0.351 ms, the step 123.2 -> 125.3 ms with the tree for every split count.  So longer split
+  // lists keep the separate reduce launch; MMIDET_WGRAD_FOLD_MAX (<= 256) moves the limit.
   static const int fold_max = getenv("MMIDET_WGRAD_FOLD_MAX") ? atoi(getenv("MMIDET_WGRAD_FOLD_MAX")) : 4;
   int cnt_per_tile = 0;
   for (int n = g.splits; n > 1; n = (n + 3) / 4) cnt_per_tile += (n + 3) / 4;
   const bool fold = g.splits > 1 && g.splits <= fold_max && (int64_t)g.mtiles * g.ntiles * cnt_per_tile <= WG_MAX_TILES && !fold_off;
-  WgradP p{};
-  p.DY = dy; p.X = x; p.OUT = g.splits > 1 ? slabs : dw;
-  p.OUTB = dbias == nullptr ? nullptr : (g.splits > 1 ? slabs + wsize : dbias);
-  p.cnt = fold ? (int*)workspace : nullptr;
-  p.cnt_per_tile = cnt_per_tile;
-  p.DW = dw; p.DB = dbias;
-  p.zero = zero_src();
-  if (p.zero == nullptr) {
-    mmi_set_error("mmi_conv_wgrad: cannot resolve the zero-source symbol");
-    return MMI_ERR_LAUNCH;
-  }
-  p.Mpix = d->N * d->Ho * d->Wo; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW;
-  p.Ho = d->Ho; p.Wo = d->Wo; p.H = d->H; p.W = d->W; p.stride = d->stride; p.pad = d->pad;
-  p.ldx = d->ldx; p.ldy = d->ldy; p.Ntot = d->KH * d->KW * d->Cin; p.chunk = g.chunk;
-  p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = g.splits > 1 ? slab : 0;
-  const dim3 grid(g.mtiles * g.ntiles, g.splits), block(256);
-  hipStream_t s = (hipStream_t)stream;
   // pixel-table loaders (wgrad_kernel<..., TAB>): tap mask in 32 bits, 31-bit byte offsets into x
   bool tab = false;
+  uint32_t x_bytes_u = 0;
   if (g.vec && g_uniform_loaders && g_gemm_prec == 0 && d->KH * d->KW <= 32 && !bf16_io) {
     const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
     const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4;
     if (x_bytes < (1LL << 31)) {
       tab = true;
-      p.x_bytes = (uint32_t)x_bytes;
+      x_bytes_u = (uint32_t)x_bytes;
+    }
+  }
+  WgradP pp[2];
+  float* slabs_of[2] = {nullptr, nullptr};
+  for (int q = 0; q < nprob; ++q) {
+    MMI_CHECK_ARG(!g.vec || (((uintptr_t)dy[q] | (uintptr_t)x[q]) & (bf16_io ? 7 : 15)) == 0, "mmi_conv_wgrad: operands must be 16-byte aligned");
+    MMI_CHECK_ARG((dbias[q] != nullptr) == want_bias, "mmi_conv_wgrad2: bias gradients for both problems or for none");
+    char* ws = (char*)workspace + (size_t)q * WG_COUNTER_BYTES;   // this problem's counter block
+    float* slabs = g.splits > 1 ? (float*)((char*)workspace + (size_t)nprob * WG_COUNTER_BYTES + (size_t)q * slab_bytes) : nullptr;
+    slabs_of[q] = slabs;
+    WgradP& p = pp[q];
+    p = WgradP{};
+    p.DY = dy[q]; p.X = x[q]; p.OUT = g.splits > 1 ? slabs : dw[q];
+    p.OUTB = dbias[q] == nullptr ? nullptr : (g.splits > 1 ? slabs + wsize : dbias[q]);
+    p.cnt = fold ? (int*)ws : nullptr;
+    p.cnt_per_tile = cnt_per_tile;
+    p.DW = dw[q]; p.DB = dbias[q];
+    p.zero = zero_src();
+    if (p.zero == nullptr) {
+      mmi_set_error("mmi_conv_wgrad: cannot resolve the zero-source symbol");
+      return MMI_ERR_LAUNCH;
+    }
+    p.Mpix = d->N * d->Ho * d->Wo; p.Cout = d->Cout; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW;
+    p.Ho = d->Ho; p.Wo = d->Wo; p.H = d->H; p.W = d->W; p.stride = d->stride; p.pad = d->pad;
+    p.ldx = d->ldx; p.ldy = d->ldy; p.Ntot = d->KH * d->KW * d->Cin; p.chunk = g.chunk;
+    p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = g.splits > 1 ? slab : 0;
+    if (tab) {
+      p.x_bytes = x_bytes_u;
       p.tab = (const uint2*)table;   // (null: the kernel builds its table slab by slab)
     }
   }
+  const WgradP& p = pp[0];
+  const WgradP& q = pp[nprob - 1];
+  const dim3 grid(g.mtiles * g.ntiles, g.splits, nprob), block(256);
+  hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
-  hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p)
+  hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p, q)
   if (bf16_io) {
-#define LAUNCHWB(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4>), grid, block, 0, s, p)
+#define LAUNCHWB(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4>), grid, block, 0, s, p, q)
     if (g.bm == 128 && g.bn == 128) LAUNCHWB(128, 128);
     else if (g.bm == 128) LAUNCHWB(128, 64);
     else if (g.bn == 128) LAUNCHWB(64, 128);
@@ -818,10 +879,10 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   } else if (g.vec && g_gemm_prec >= 1) {
 #define LAUNCHW3(BM_, BN_)                                                                              \
   do {                                                                                                  \
-    if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p);  \
-    else if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p); \
-    else if (g_gemm_prec == 5) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 5>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3>), grid, block, 0, s, p);                   \
+    if (g_gemm_prec == 1) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 1>), grid, block, 0, s, p, q);  \
+    else if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2>), grid, block, 0, s, p, q); \
+    else if (g_gemm_prec == 5) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 5>), grid, block, 0, s, p, q); \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3>), grid, block, 0, s, p, q);                   \
   } while (0)
     if (g.bm == 128 && g.bn == 128) LAUNCHW3(128, 128);
     else if (g.bm == 128) LAUNCHW3(128, 64);
@@ -830,7 +891,7 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
 #undef LAUNCHW3
   } else if (!g.vec) LAUNCHW(64, 64, false);
   else if (tab) {
-#define LAUNCHWT(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 0, true>), grid, block, 0, s, p)
+#define LAUNCHWT(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 0, true>), grid, block, 0, s, p, q)
     if (g.bm == 128 && g.bn == 128) LAUNCHWT(128, 128);
     else if (g.bm == 128) LAUNCHWT(128, 64);
     else if (g.bn == 128) LAUNCHWT(64, 128);
@@ -844,9 +905,9 @@ int conv_wgrad_impl(const float* dy, const float* x, float* dw, float* dbias, vo
   MMI_CHECK_LAUNCH("mmi_conv_wgrad");
   if (g.splits > 1 && !fold) {
     // without dbias only the weight part [0, wsize) of every slab is reduced
-    const int64_t count = dbias != nullptr ? slab : wsize;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(count, 1024)), dim3(256), 0, s, (const float*)slabs, dw, dbias, wsize, slab, count,
-                       g.splits);
+    const int64_t count = want_bias ? slab : wsize;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(count, 1024), nprob), dim3(256), 0, s, (const float*)slabs_of[0], dw[0], dbias[0],
+                       (const float*)slabs_of[nprob - 1], dw[nprob - 1], dbias[nprob - 1], wsize, slab, count, g.splits);
     MMI_CHECK_LAUNCH("mmi_conv_wgrad(reduce)");
   }
   return MMI_OK;

@@ -38,6 +38,21 @@ class LinearEpilogue(Structure):
 
 EPI_NONE, EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_ACCUMULATE = 0, 1, 2, 3, 4
 
+
+class BnMap(Structure):
+    """mmi_bn_map (include/mmidet_hip.h): parameter blocks + output scatter of a BatchNorm pass over a multi-module buffer."""
+    _fields_ = [('gamma', c_void_p * 4), ('beta', c_void_p * 4), ('dgamma', c_void_p * 4), ('dbeta', c_void_p * 4),
+                ('nblk', c_int32), ('blk', c_int32), ('period', c_int32), ('split', c_int32), ('ls0', c_int32), ('ls1', c_int32)]
+
+
+PtrPair = c_void_p * 2
+BnStatsPair = BnStats * 2
+
+
+def ptr_pair(a, b):
+    return PtrPair(a, b)
+
+
 P = c_void_p
 _SIGS = {
     'mmi_version': (c_int, []),
@@ -69,6 +84,16 @@ _SIGS = {
     'mmi_conv_wgrad_table_bytes': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_wgrad_table_build': (c_int, [P, POINTER(ConvDesc), P]),
     'mmi_conv_wgrad_tab': (c_int, [P, P, P, P, P, c_size_t, P, POINTER(ConvDesc), P]),
+    'mmi_bn_act_fwd_map': (c_int, [P, c_int, P, POINTER(BnMap), P, c_int, P, c_int, P, c_int, c_int64, c_int, c_int, P]),
+    'mmi_bn_act_bwd_map': (c_int, [P, c_int, P, c_int, P, c_int, P, POINTER(BnMap), P, c_size_t, P, c_int, c_int64, c_int, c_int, c_int, P]),
+    'mmi_conv_fwd_row_blocks_n': (c_int, [POINTER(ConvDesc), c_int]),
+    'mmi_conv_fwd_workspace_n': (c_size_t, [POINTER(ConvDesc), c_int]),
+    'mmi_conv_dgrad_workspace_n': (c_size_t, [POINTER(ConvDesc), c_int]),
+    'mmi_conv_wgrad_workspace_n': (c_size_t, [POINTER(ConvDesc), c_int]),
+    'mmi_conv_bn_fwd2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(BnStatsPair), c_int, P, c_size_t,
+                                 POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), c_int, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_wgrad2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), P, c_size_t, P, POINTER(ConvDesc), P]),
     'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
     'mmi_bn_eval_stats': (c_int, [P, P, c_int, c_float, P, P]),
     'mmi_bn_act_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_int, c_int64, c_int, c_int, P]),
@@ -81,6 +106,7 @@ _SIGS = {
     'mmi_u8_pair_to_nhwc': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'mmi_nhwc_to_nchw': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_space_to_depth': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mmi_space_to_depth_ld': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_head_permute': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_add': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_copy2d': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
@@ -153,7 +179,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

@@ -63,6 +63,13 @@ def conv_fwd(x, w, bias, y, part, d, s):
                  part.data_ptr() if part is not None else None, ws.data_ptr() if nb else None, nb, d, s)
 
 
+def conv_fwd_raw(xp, wp, yp, d, device, s):
+    """mmi_conv_fwd on raw addresses (no bias, no statistics): the inference form of a lane of a twin layer."""
+    nb = fwd_plan(d)[0]
+    ws = zeroed_scratch(nb, device, s) if nb else None
+    lib.conv_fwd(xp, wp, None, yp, None, ws.data_ptr() if nb else None, nb, d, s)
+
+
 _dgrad_ws = {}
 _wgrad_ws = {}
 _bnbwd_ws = {}

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from mmidet_hip import fusion_ops as F2
 from mmidet_hip import ops
+from mmidet_hip import twin_ops as T2
 from mmidet_hip.ops import ACT_LEAKY, ACT_NONE, ACT_SILU
 
 
@@ -61,6 +62,16 @@ class Conv(nn.Module):
                                residual=residual, training=self.bn.training, eps=self.bn.eps,
                                momentum=self.bn.momentum, skip=skip, dest=dest)
 
+    def twin_ok(self, other):
+        """Can this layer and `other` (the same layer of the other backbone) run as one twin launch (mmidet_hip/twin_ops.py)?"""
+        return (type(other) is type(self) and hasattr(self, 'bn') and hasattr(other, 'bn') and self.conv.weight.shape == other.conv.weight.shape
+                and self.conv.stride == other.conv.stride and self._act_id() == other._act_id() and self.bn.eps == other.bn.eps
+                and self.bn.momentum == other.bn.momentum and self.bn.training == other.bn.training)
+
+    def twin(self, other, x, residual=None, skip=False, dest=None):
+        """Both backbones' copies of this layer on a twin tensor (N,H,W,2,C): one GEMM launch, one normalise pass."""
+        return T2.conv_bn_act2(x, self, other, residual=residual, skip=skip, dest=dest)
+
     def fuseforward(self, x, residual=None):
         """After Model.fuse() (models/common.py:124-125): the folded conv carries the bias, BN is gone."""
         return ops.conv_bias_act(x, self.conv.weight, self.conv.bias, stride=self.conv.stride[0], act=self._act_id(),
@@ -83,6 +94,15 @@ class Bottleneck(nn.Module):
                 return self.cv2(h, residual=xs, dest=dest)
             return self.cv2(self.cv1(x), residual=x if self.add else None, dest=dest)
         return self.cv2(self.cv1(x), residual=x if self.add else None)        # after Model.fuse()
+
+    def twin_ok(self, other):
+        return type(other) is type(self) and self.add == other.add and self.cv1.twin_ok(other.cv1) and self.cv2.twin_ok(other.cv2)
+
+    def twin(self, other, x, dest=None):
+        if self.add and ops.SKIP_FUSE:
+            h, xs = self.cv1.twin(other.cv1, x, skip=True)
+            return self.cv2.twin(other.cv2, h, residual=xs, dest=dest)
+        return self.cv2.twin(other.cv2, self.cv1.twin(other.cv1, x), residual=x if self.add else None, dest=dest)
 
 
 class C3(nn.Module):
@@ -130,6 +150,22 @@ class C3(nn.Module):
             h = blk(h, dest=(cat, 0) if i == last else None)
         return self.cv3(ops.cat_alias(h, b_out, cat))
 
+    def twin_ok(self, other):
+        return (type(other) is type(self) and len(self.m) == len(other.m) and ops.PACK_C3 and self.packed() and other.packed()
+                and self.cv1.twin_ok(other.cv1) and self.cv2.twin_ok(other.cv2) and self.cv3.twin_ok(other.cv3)
+                and all(a.twin_ok(b) for a, b in zip(self.m, other.m)))
+
+    def twin(self, other, x):
+        """Both backbones' C3 on a twin tensor: cv1|cv2 of both lanes as one GEMM, the lanes' concat buffers side by side
+        (N,H,W,2,2c_) and written in place by their producers, cv3 of both lanes as one GEMM."""
+        c_ = self.cv1.conv.weight.shape[0]
+        cat = torch.empty((*x.shape[:3], 2, 2 * c_), dtype=x.dtype, device=x.device)
+        h, b_out = T2.dual_conv_bn_act2(x, self, other, ops.Dest(cat))
+        last = len(self.m) - 1
+        for i, (ba, bb) in enumerate(zip(self.m, other.m)):
+            h = ba.twin(bb, h, dest=ops.Dest(cat[..., :c_]) if i == last else None)
+        return self.cv3.twin(other.cv3, ops.cat_alias(h, b_out, ops.Dest(cat)))
+
 
 class SPP(nn.Module):
     def __init__(self, c1, c2, k=(5, 9, 13)):
@@ -143,6 +179,12 @@ class SPP(nn.Module):
     def forward(self, x):
         return self.cv2(ops.spp_pool(self.cv1(x)))
 
+    def twin_ok(self, other):
+        return type(other) is type(self) and self.cv1.twin_ok(other.cv1) and self.cv2.twin_ok(other.cv2)
+
+    def twin(self, other, x):
+        return self.cv2.twin(other.cv2, T2.spp_pool2(self.cv1.twin(other.cv1, x)))
+
 
 class Focus(nn.Module):
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
@@ -151,6 +193,13 @@ class Focus(nn.Module):
 
     def forward(self, x):
         return self.conv(ops.space_to_depth(x))
+
+    def twin_ok(self, other):
+        return type(other) is type(self) and self.conv.twin_ok(other.conv)
+
+    def twin(self, other, xa, xb):
+        """Both stems: the two images' slicings side by side (N,H/2,W/2,2,12), one twin conv."""
+        return self.conv.twin(other.conv, T2.space_to_depth2(xa, xb))
 
 
 class Concat(nn.Module):
@@ -169,6 +218,9 @@ class Add(nn.Module):
 
     def forward(self, x):
         return ops.add(x[0], x[1])
+
+    def twin(self, x):
+        return T2.add_lanes(x)
 
 
 class FusedTokens:
@@ -190,6 +242,15 @@ class Add2(nn.Module):
         if isinstance(x[1], FusedTokens):
             return F2.upsample_add(x[0], x[1].maps[self.index])
         return ops.add(x[0], x[1][self.index])
+
+    def twin_ok(self, other):
+        return type(other) is type(self) and self.index == 0 and other.index == 1
+
+    def twin(self, other, x, fused):
+        """The Add2 pair of a fusion point on the twin tensor of the two streams: lane g + up-sampled transformer map g."""
+        if isinstance(fused, FusedTokens):
+            return T2.upsample_add2(x, fused.maps[0], fused.maps[1])
+        return None
 
 
 class EnhanceConv2d(nn.Module):
@@ -334,16 +395,26 @@ class GPT(nn.Module):
 
     fan_skip = True      # forward(x, skip=True) -> (output, [rgb alias, ir alias]) for the maps' other consumers (yolo_test.forward_once)
 
-    def forward(self, x, skip=False):
+    def _pool(self, x, skip):
+        """tokens (B,128,C), alias list (or None), (H, W): x is the pair (rgb, ir) of maps or their twin tensor (N,H,W,2,C)."""
+        if torch.is_tensor(x) and x.dim() == 5:
+            pooled = T2.pool_tokens2(x, skip)
+            if skip:
+                return pooled[0], [pooled[1]], tuple(x.shape[1:3])
+            return pooled, None, tuple(x.shape[1:3])
         rgb, ir = x[0], x[1]
         assert rgb.shape[0] == ir.shape[0]
         pooled = F2.pool_tokens(rgb, ir, skip)
         alias = None
         if skip:
             pooled, *alias = pooled
+        return pooled, alias, tuple(rgb.shape[1:3])
+
+    def forward(self, x, skip=False):
+        pooled, alias, hw = self._pool(x, skip)
         y = self._transform(pooled)
         a, b = F2.split_tokens(y)
-        out = FusedTokens(a, b, tuple(rgb.shape[1:3]))
+        out = FusedTokens(a, b, hw)
         return (out, alias) if skip else out
 
 
@@ -359,13 +430,8 @@ class GPT1_fourier(GPT):
         self.conv2 = _holder_conv(8, d_model, 1, 1)
 
     def forward(self, x, skip=False):
-        rgb, ir = x[0], x[1]
-        assert rgb.shape[0] == ir.shape[0]
-        bs, c = rgb.shape[0], rgb.shape[-1]
-        pooled = F2.pool_tokens(rgb, ir, skip)                               # (B,128,C): rgb tokens then ir tokens
-        alias = None
-        if skip:
-            pooled, *alias = pooled
+        pooled, alias, hw = self._pool(x, skip)                              # (B,128,C): rgb tokens then ir tokens
+        bs, c = pooled.shape[0], pooled.shape[-1]
         gate = F2.sigmoid(ops.conv_bias(pooled, self.conv1.weight.view(8, c), None, 1))   # (B,128,8)
         with torch.no_grad():                                                # pattern loss: value only
             hi = F2.ffm_highpass_mul(pooled.detach().view(bs * 2, 64, c))
@@ -376,7 +442,7 @@ class GPT1_fourier(GPT):
         y = self._transform(F2.mul(pt, pooled))
         self.last_tokens = y.detach()
         a, b = F2.split_tokens(y)
-        out = FusedTokens(a, b, tuple(rgb.shape[1:3]))
+        out = FusedTokens(a, b, hw)
         return ((out, self.pattenLoss), alias) if skip else (out, self.pattenLoss)
 
 

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from mmidet_hip import fusion_ops as F2
 from mmidet_hip import ops
+from mmidet_hip import twin_ops as T2
 from models.common import (C3, GPT, SPP, Add, Add2, AdaptiveModule3, Bottleneck, Concat, Conv, Focus, FusedTokens,
                            GPT1_fourier, _holder_conv)
 from utils.autoanchor import check_anchor_order
@@ -35,6 +36,16 @@ def _tensors_of(obj):
     if isinstance(obj, (list, tuple)):
         return [t for o in obj for t in _tensors_of(o)]
     return []
+
+
+class Lane:
+    """Placeholder for one lane (0 = RGB, 1 = IR) of the twin tensor a layer pair produced (Model._twin_out[leader]): what the
+    saved-output list holds for layers that ran as a twin launch.  Twin-aware consumers take the twin tensor itself; anything
+    else gets the lane as an (N,H,W,C) view through Model._single()."""
+    __slots__ = ('leader', 'g')
+
+    def __init__(self, leader, g):
+        self.leader, self.g = leader, g
 
 
 class Upsample2x(nn.Upsample):
@@ -151,6 +162,47 @@ class Model(nn.Module):
             if len(c) == 2 and c[0] != c[1] and getattr(first, 'fan_skip', False) and os.environ.get('MMIDET_FAN_SKIP', '1') != '0':
                 if isinstance(first.f, int) or isinstance(first, GPT):
                     self._fan_skip.setdefault(c[0], []).append(j)
+        self._plan_twins(cons)
+
+    def _plan_twins(self, cons):
+        """Twin plan: pair every IR-backbone layer (follower) with the RGB-backbone layer (leader) that is the same module on the
+        other stream -- same type, same parameter shapes, and inputs that are themselves such a pair (or the two images) -- so that
+        forward_once can run the pair as ONE set of launches over a twin tensor (mmidet_hip/twin_ops.py).  The default YAML pairs
+        rows (0,3) (1,4) (2,5) (7,8) (9,11) (10,12) ...; the fusion_add graphs pair row i with row i + 10."""
+        self._leader_of, self._follower_of, self._twin_fan = {}, {}, {}
+        self.twin = os.environ.get('MMIDET_TWIN', '1') != '0'
+        lanes, srcs = self._lanes, self._srcs
+        shapes = lambda m: [tuple(p.shape) for p in m.parameters()]   # noqa: E731
+        for j, mj in enumerate(self.model):
+            if not lanes[j] or not hasattr(mj, 'twin_ok'):
+                continue
+            for i in range(j):
+                mi = self.model[i]
+                if lanes[i] or i in self._follower_of or type(mi) is not type(mj) or shapes(mi) != shapes(mj):
+                    continue
+                si, sj = srcs[i], srcs[j]
+                if isinstance(mj, Focus):
+                    ok = mj.f == -4 and mi.f == -1 and i == 0
+                elif isinstance(mj, Add2):
+                    ok = (len(si) == 2 and len(sj) == 2 and self._leader_of.get(sj[0]) == si[0] and si[1] == sj[1]
+                          and mi.index == 0 and mj.index == 1)
+                else:
+                    ok = isinstance(mj.f, int) and len(si) == 1 and len(sj) == 1 and self._leader_of.get(sj[0]) == si[0]
+                if ok:
+                    self._follower_of[i], self._leader_of[j] = j, i
+                    break
+        # fan-out plan of the twin tensors (see _plan_lanes): a pair's output with exactly two consuming executions whose first
+        # can hand its input on (a Conv pair, a fusion transformer's token pooling) is consumed as (output, alias) there
+        for lead, fol in self._follower_of.items():
+            execs = []
+            for c in sorted(set(cons.get(lead, []) + cons.get(fol, []))):
+                e = self._leader_of.get(c, c)
+                if e not in execs:
+                    execs.append(e)
+            if len(execs) == 2 and os.environ.get('MMIDET_FAN_SKIP', '1') != '0':
+                first = self.model[execs[0]]
+                if isinstance(first, GPT) or (isinstance(first, Conv) and execs[0] in self._follower_of):
+                    self._twin_fan[execs[0]] = lead
 
     def __getstate__(self):
         """Pickling (train.py:881-899 stores whole model objects) and deepcopy (ModelEMA): HIP stream handles stay behind."""
@@ -160,7 +212,7 @@ class Model(nn.Module):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        if '_lanes' not in state or '_fan_skip' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
+        if '_lanes' not in state or '_fan_skip' not in state or '_leader_of' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
             self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
             self._plan_lanes()
 
@@ -206,9 +258,13 @@ class Model(nn.Module):
         self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = empty
         x = ops.nchw_to_nhwc(x)
         x2 = ops.nchw_to_nhwc(x2)
-        # The twin backbones are independent between fusion points: the IR lane runs on its own HIP stream so that its
-        # kernels fill the partial last wave of the RGB lane's (and vice versa); autograd replays the same streams in
-        # backward.  Events order every cross-lane hand-off.
+        bf16 = getattr(self, 'storage', 'f32') == 'bf16'
+        # Twin launches (mmidet_hip/twin_ops.py): every layer pair of the two backbones runs as one set of launches over a twin
+        # tensor, on the caller's stream.  Layers outside a pair (and every layer when MMIDET_TWIN=0, in the bf16 storage mode or
+        # after fuse()) take the lane form: the IR backbone on its own HIP stream, events at every cross-lane hand-off.
+        twin = getattr(self, 'twin', False) and x.is_cuda and not bf16 and x.dtype == torch.float32
+        if twin:
+            self._pack_for_twin()
         lanes = self._lanes if (self.two_streams and x.is_cuda) else None
         main = torch.cuda.current_stream() if lanes else None
         if lanes:
@@ -221,20 +277,99 @@ class Model(nn.Module):
         hook = getattr(self, '_tail_hook', None)
         if hook is not None and x.requires_grad:                   # (TrainStep's early optimizer: see _on_tail_gradient)
             x.register_hook(hook)
-        bf16 = getattr(self, 'storage', 'f32') == 'bf16'
-        fan = self._fan_skip if torch.is_grad_enabled() else {}
+        grad = torch.is_grad_enabled()
+        fan = self._fan_skip if grad else {}
+        tfan = self._twin_fan if grad else {}
+        self._twin_out, self._twin_lanes = {}, {}                  # leader index -> twin tensor / its two lane views
+        tw = self._twin_out
         y = []
         prev = x
+
+        def resolve(m):
+            if m.f == -1:
+                return prev
+            if m.f == -4:
+                return x2
+            return y[m.f] if isinstance(m.f, int) else [prev if j == -1 else y[j] for j in m.f]
+
+        def twin_of(v):
+            """The twin tensor behind a pair of inputs [Lane(L,0), Lane(L,1)] of one pair's output, else None."""
+            if (isinstance(v, (list, tuple)) and len(v) == 2 and isinstance(v[0], Lane) and isinstance(v[1], Lane)
+                    and v[0].leader == v[1].leader and (v[0].g, v[1].g) == (0, 1) and v[0].leader in tw):
+                return v[0].leader
+            return None
+
         for m in self.model:
-            if m.f != -1 and m.f != -4:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            i = m.i
+            if twin and i in self._leader_of and self._leader_of[i] in tw:      # ran with its leader
+                prev = Lane(self._leader_of[i], 1)
+                y.append(prev if i in self.save else None)
+                continue
+            xin = resolve(m)
+            out = None
+            on_ir = bool(lanes and lanes[i])
+            j = self._follower_of.get(i) if twin else None
+            if j is not None and m.twin_ok(self.model[j]):
+                mj = self.model[j]
+                if isinstance(m, Focus):
+                    if lanes:
+                        main.wait_stream(ir)                       # (x2's layout pass ran there)
+                    out = m.twin(mj, self._single(xin), x2)
+                elif isinstance(m, Add2):
+                    lead = xin[0].leader if isinstance(xin[0], Lane) and xin[0].g == 0 and xin[0].leader in tw else None
+                    if lead is not None and self._leader_of.get(self._srcs[j][0]) == lead:
+                        out = m.twin(mj, tw[lead], xin[1])
+                elif isinstance(xin, Lane) and xin.g == 0 and xin.leader in tw:
+                    if i in tfan:
+                        out, alias = m.twin(mj, tw[xin.leader], skip=True)
+                        tw[tfan[i]] = alias
+                        self._twin_lanes.pop(tfan[i], None)
+                    else:
+                        out = m.twin(mj, tw[xin.leader])
+                if out is not None:
+                    tw[i] = out
+                    prev = Lane(i, 0)
+                    y.append(prev if i in self.save else None)
+                    continue
+            # ---- not a twin pair (or one that cannot run as such right now): twin-aware consumers of a pair's output, then the lane form
+            lead = twin_of(xin) if twin else None
+            if lead is not None and isinstance(m, GPT):
+                if isinstance(m, GPT1_fourier):
+                    T = tw[lead]
+                    if i in tfan:
+                        (x, pt), alias = m(T, skip=True)
+                        tw[tfan[i]] = alias[0]
+                        self._twin_lanes.pop(tfan[i], None)
+                    else:
+                        x, pt = m(T)
+                    with torch.no_grad():                          # CBM + IGM: values only (detached in the reference)
+                        st = F2.fusion_stats(T[..., 0, :], T[..., 1, :], m.last_tokens)
+                    self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
+                elif i in tfan:
+                    x, alias = m(tw[lead], skip=True)
+                    tw[tfan[i]] = alias[0]
+                    self._twin_lanes.pop(tfan[i], None)
+                else:
+                    x = m(tw[lead])
+                prev = x
+                y.append(x if i in self.save else None)
+                continue
+            if lead is not None and isinstance(m, Add):
+                prev = x = m.twin(tw[lead])
+                y.append(x if i in self.save else None)
+                continue
+            from_twin = twin and any(isinstance(v, Lane) for v in (xin if isinstance(xin, (list, tuple)) else [xin]))
+            xin = self._single(xin)
+            x = xin
             if lanes:
-                st_ = ir if lanes[m.i] else main
-                for j in self._srcs[m.i]:                          # hand-offs from the other lane
-                    if lanes[j] != lanes[m.i]:
-                        st_.wait_event(done[j])
+                st_ = ir if on_ir else main
+                if on_ir and from_twin:
+                    ir.wait_stream(main)                           # twin launches run on the caller's stream
+                for k in self._srcs[i]:                            # hand-offs from the other lane
+                    if k in done and done[k][1] is not st_:
+                        st_.wait_event(done[k][0])
                         if not torch.cuda.is_current_stream_capturing():   # (a graph's private pool replays fixed addresses)
-                            for t in _tensors_of(y[j] if y[j] is not None else prev):   # unsaved => j is the previous layer
+                            for t in _tensors_of(self._single(y[k]) if y[k] is not None else xin):   # unsaved => k is the previous layer
                                 t.record_stream(st_)
                 ctx = torch.cuda.stream(st_)
                 ctx.__enter__()
@@ -244,38 +379,65 @@ class Model(nn.Module):
                     x = ops.cast(x, torch.bfloat16)
             elif isinstance(m, GPT1_fourier):
                 in_rgb, in_ir = x[0], x[1]
-                if m.i in fan:
+                if i in fan:
                     (x, pt), alias = m(x, skip=True)
-                    for j, a in zip(self._srcs[m.i], alias):
-                        y[j] = a
+                    for k, a in zip(self._srcs[i], alias):
+                        y[k] = a
                 else:
                     x, pt = m(x)
                 with torch.no_grad():                              # CBM + IGM: values only (detached in the reference)
                     st = F2.fusion_stats(in_rgb, in_ir, m.last_tokens)
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
-                if m.i in fan:                                     # (output, alias of the input for its second consumer)
+                if i in fan and not any(isinstance(y[k], Lane) for k in self._srcs[i]):   # (output, alias of the input for its second consumer)
                     x, alias = m(x, skip=True)
                     if isinstance(alias, (list, tuple)):
-                        for j, a in zip(self._srcs[m.i], alias):
-                            y[j] = a
+                        for k, a in zip(self._srcs[i], alias):
+                            y[k] = a
                     else:
-                        y[self._srcs[m.i][0]] = alias
+                        y[self._srcs[i][0]] = alias
                 else:
                     x = m(x)
-                if bf16 and m.i == 0:
+                if bf16 and i == 0:
                     x = ops.cast(x, torch.bfloat16)          # behind the RGB stem (Focus): everything downstream is bf16
             if lanes:
                 ev = torch.cuda.Event()
                 ev.record(st_)
-                done[m.i] = ev
+                done[i] = (ev, st_)
                 ctx.__exit__(None, None, None)
             prev = x
-            y.append(x if m.i in self.save else None)
+            y.append(x if i in self.save else None)
         if lanes:
             main.wait_stream(ir)
+        self._twin_out, self._twin_lanes = {}, {}
         self.Combine_loss = self.SSIMloss                          # yolo_test.py:266-268 (detached SSIM term)
         return x, self.Combine_loss
+
+    def _pack_for_twin(self):
+        """C3's cv1 | cv2 run as one GEMM -- and the two backbones' C3 as one twin launch -- only when their parameters share
+        buffers (ops.pack_pair: same Parameters, state_dict keys and values).  TrainStep packs before it builds its optimizer;
+        a caller that drives the model itself (the reference's train.py / test.py) gets the packing at its first forward on the
+        device.  Never while a data-parallel reducer holds gradient slots keyed on the parameter addresses."""
+        w = next((p for p in self.parameters() if p.is_cuda), None)
+        key = (w.data_ptr(), w._version) if w is not None else None
+        if key is None or getattr(self, '_pack_key', None) == key or ops.GRAD_SLOTS or torch.cuda.is_current_stream_capturing():
+            return
+        if ops.PACK_C3:
+            ops.pack_pair(self)
+        w = next(p for p in self.parameters() if p.is_cuda)
+        self._pack_key = (w.data_ptr(), w._version)
+
+    def _single(self, v):
+        """Inputs of a single-lane layer: Lane placeholders become (N,H,W,C) views of their twin tensor (one autograd node per
+        twin tensor: the two lanes' gradients come back together)."""
+        if isinstance(v, Lane):
+            views = self._twin_lanes.get(v.leader)
+            if views is None:
+                views = self._twin_lanes[v.leader] = T2.lanes(self._twin_out[v.leader])
+            return views[v.g]
+        if isinstance(v, (list, tuple)):
+            return [self._single(t) for t in v]
+        return v
 
     def _initialize_biases(self, cf=None):
         m = self.model[-1]
@@ -296,6 +458,7 @@ class Model(nn.Module):
                 delattr(m, 'bn')
                 m.forward = m.fuseforward
         self._fan_skip = {}                                        # (fuseforward has no hand-on form; inference does not need one)
+        self._twin_fan, self.twin = {}, False
         self.info()
         return self
 
