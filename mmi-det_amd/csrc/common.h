@@ -36,6 +36,10 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // bn.hip: fp64 fold of partials[part][2][C] into out0[C] (slot 0) and out1[C] (slot 1)
 int mmi_pair_colsum(float* partials, int nparts, int C, float* out0, float* out1, void* stream);  // consumes partials
 int mmi_i64_increment(int64_t* counter, void* stream);   // bn.hip: *counter += 1
+// api.hip: fill `bytes` bytes (a multiple of 4, 4-byte aligned) with the byte `value` -- a KERNEL, not hipMemsetAsync: inside a
+// captured step a memset NODE was observed out of order with its neighbouring kernel nodes when the whole step is one stream
+// (ROCm 7.2; profiles/r03_graph_memset_nodes.txt), a kernel node is ordered like every other launch
+int mmi_fill_bytes(void* ptr, int value, size_t bytes, hipStream_t stream);
 // cem.hip: direct VALU convolutions for the 3<->24-channel CEM layers, reached through the public conv entry points
 bool mmi_smallconv_supported(const mmi_conv_desc* d);
 bool mmi_smallconv_dgrad_supported(const mmi_conv_desc* d);

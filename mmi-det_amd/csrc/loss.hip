@@ -299,12 +299,10 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
   w += (size_t)nl * capn * MAX_NO * sizeof(float);
   int* owner = (int*)w;
   int* cnt = owner + total;
-  if (hipMemsetAsync(P.acc, 0, (size_t)nl * ACC_STRIDE * sizeof(double), s) != hipSuccess ||
-      hipMemsetAsync(owner, 0xFF, (size_t)total * sizeof(int), s) != hipSuccess ||
-      hipMemsetAsync(cnt, 0, (size_t)total * sizeof(int), s) != hipSuccess) {
-    mmi_set_error("mmi_detect_loss: memset failed");
-    return MMI_ERR_LAUNCH;
-  }
+  // (fill KERNELS, not hipMemsetAsync: common.h::mmi_fill_bytes)
+  if (int e = mmi_fill_bytes(P.acc, 0, (size_t)nl * ACC_STRIDE * sizeof(double), s)) return e;
+  if (int e = mmi_fill_bytes(owner, 0xFF, (size_t)total * sizeof(int), s)) return e;
+  if (int e = mmi_fill_bytes(cnt, 0, (size_t)total * sizeof(int), s)) return e;
   int64_t off = 0, maxcells = 0;
   for (int l = 0; l < nl; ++l) {
     P.p[l] = preds[l];
@@ -314,10 +312,7 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
     off += P.cells[l];
     P.balance[l] = balance_host[l];
     if (P.cells[l] > maxcells) maxcells = P.cells[l];
-    if (hipMemsetAsync(dpreds[l], 0, (size_t)P.cells[l] * (nc + 5) * sizeof(float), s) != hipSuccess) {
-      mmi_set_error("mmi_detect_loss: memset failed");
-      return MMI_ERR_LAUNCH;
-    }
+    if (int e = mmi_fill_bytes(dpreds[l], 0, (size_t)P.cells[l] * (nc + 5) * sizeof(float), s)) return e;
   }
   P.idx = idx; P.tcls = tcls; P.tbox = tbox; P.anch = anch; P.counts = counts;
   P.nl = nl; P.na = na; P.no = nc + 5; P.nc = nc; P.cap = (int)cap; P.bs = bs;

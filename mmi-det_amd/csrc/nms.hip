@@ -193,10 +193,7 @@ extern "C" int mmi_nms(const float* pred, int B, int64_t R, int nc, float conf_t
   w.cls = (int*)base;
   base += (size_t)B * cap * 4;
   w.key = (int*)base;
-  if (hipMemsetAsync(w.count, 0, (size_t)B * 4, s) != hipSuccess) {
-    mmi_set_error("mmi_nms: hipMemsetAsync failed");
-    return MMI_ERR_LAUNCH;
-  }
+  if (int e = mmi_fill_bytes(w.count, 0, (size_t)B * 4, s)) return e;
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(nms_blocks((int64_t)B * R)), dim3(256), 0, s, pred, B, R, nc, conf_thres,
                      multi_label, class_allow, cap, w);
   MMI_CHECK_LAUNCH("mmi_nms(candidates)");

@@ -484,10 +484,7 @@ extern "C" int mmi_fusion_stats(const float* in_rgb, int lda, const float* in_ir
   MMI_CHECK_ARG(in_rgb && in_ir && tokens && workspace && out3 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 &&
                     lda % 4 == 0 && ldb % 4 == 0, "mmi_fusion_stats: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, mmi_fusion_stats_workspace(), s) != hipSuccess) {
-    mmi_set_error("mmi_fusion_stats: memset failed");
-    return MMI_ERR_LAUNCH;
-  }
+  if (int e = mmi_fill_bytes(workspace, 0, mmi_fusion_stats_workspace(), s)) return e;
   double* acc = (double*)workspace;
   unsigned int* hist = (unsigned int*)(acc + 11);
   const int64_t npix = (int64_t)N * H * W;

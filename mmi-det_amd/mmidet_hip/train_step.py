@@ -235,17 +235,13 @@ class TrainStep:
         return self._loss, self._items
 
     def _capture(self, imgs_u8, targets):
-        # The captured step keeps ONE level of stream forking: the twin backbone lanes (RGB/IR on two HIP streams).
-        # Confirmed cause (tools/capture_probe.py, profiles/r02_capture_probe.txt): hipStreamEndCapture of ROCm 7.2 segfaults
-        # whenever a stream forked from a NON-origin capturing stream (lane -> its wgrad stream) is joined back into that
-        # stream; three plain torch kernels on main -> A -> B with B joined into A reproduce it, and the same B joined into
-        # the capture's origin stream is fine.  The per-layer dgrad||wgrad fork/join inside the IR lane is exactly that
-        # pattern (inside the RGB lane, which IS the origin, it is fine: "step:wgrad" passes).  The deferred-join form
-        # (wgrad streams joined once, into the origin) captures, but replays slower than no overlap (158 vs 153 ms/step),
-        # so wgrad overlap stays an eager-mode feature and is off while capturing.
+        # Which stream forks survive a capture (tools/capture_probe.py, profiles/r02_capture_probe.txt): hipStreamEndCapture of
+        # ROCm 7.2 segfaults whenever a stream forked from a NON-origin capturing stream (IR lane -> its wgrad stream) is joined
+        # back into that stream; forks from the origin stream are fine.  With twin launches (models/yolo_test.py) both backbones
+        # run on the origin stream, so the wgrad side streams fork from the origin only and the captured step KEEPS the
+        # dgrad || wgrad overlap.  Only when the IR lane stream carries work of its own (MMIDET_TWIN=0, the bf16 storage mode, a
+        # graph whose backbones do not pair up) does the capture fall back to weight gradients on the lanes' own streams.
         prev = ops.OVERLAP_WGRAD
-        if self.model.two_streams and not getattr(self, '_capture_keeps_wgrad_overlap', False):   # (tools/capture_probe.py)
-            ops.OVERLAP_WGRAD = False
         try:
             self._capture_locked(imgs_u8, targets)
         finally:
@@ -261,6 +257,9 @@ class TrainStep:
                 self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if (self.model.two_streams and getattr(self.model, '_ir_used', True)
+                and not getattr(self, '_capture_keeps_wgrad_overlap', False)):   # (tools/capture_probe.py)
+            ops.OVERLAP_WGRAD = False
         self._graph = torch.cuda.CUDAGraph()
         if self.reducer is not None:
             self.reducer.enabled = False                   # no collectives inside the capture: see _graph_step

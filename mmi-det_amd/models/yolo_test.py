@@ -281,6 +281,7 @@ class Model(nn.Module):
         fan = self._fan_skip if grad else {}
         tfan = self._twin_fan if grad else {}
         self._twin_out, self._twin_lanes = {}, {}                  # leader index -> twin tensor / its two lane views
+        self._ir_used = False
         tw = self._twin_out
         y = []
         prev = x
@@ -363,6 +364,7 @@ class Model(nn.Module):
             x = xin
             if lanes:
                 st_ = ir if on_ir else main
+                self._ir_used = self._ir_used or on_ir
                 if on_ir and from_twin:
                     ir.wait_stream(main)                           # twin launches run on the caller's stream
                 for k in self._srcs[i]:                            # hand-offs from the other lane

@@ -122,6 +122,31 @@ def test_whole_step_graph_matches_eager():
     close(ts1.ema.ema.model[1].conv.weight, ts2.ema.ema.model[1].conv.weight, what='ema', tol=1e-5)
 
 
+@pytest.mark.parametrize('twin', ['1', '0'])
+def test_single_stream_capture_matches_eager(monkeypatch, twin):
+    """The whole step captured on ONE stream (no backbone lanes, no wgrad side streams): round 3 found that such a capture
+    replayed correctly once and then returned a NaN SSIM term and a wrong objectness loss -- hipMemsetAsync nodes of a
+    single-stream hipGraph lose their order on this ROCm (tools/graph_memset_probe.py, profiles/r03_graph_memset_nodes.txt), and
+    mmi_fusion_stats / mmi_detect_loss zeroed their accumulators that way.  The library zeroes with a kernel now
+    (common.h::mmi_fill_bytes); forked captures had masked the problem."""
+    from mmidet_hip import ops
+    monkeypatch.setenv('MMIDET_TWIN', twin)
+    monkeypatch.setenv('MMIDET_TWO_STREAMS', '0')
+    monkeypatch.setattr(ops, 'OVERLAP_WGRAD', False)
+    m1, ts1, cfg = make(graph=True)
+    m2, ts2, _ = make(graph=False)
+    assert not m1.two_streams
+    batches = [batch(cfg, 30 + i) for i in range(4)]
+    for _ in range(2):
+        ts2.step(*batches[0])
+    for imgs, tg in batches:
+        l1, i1 = ts1.step(imgs, tg)
+        l2, i2 = ts2.step(imgs, tg)
+        close(l1, l2, what='loss', tol=1e-5)
+        close(i1, i2, what='items', tol=1e-5)
+    close(m1.model[1].conv.weight, m2.model[1].conv.weight, what='weights after 4 replays', tol=1e-5)
+
+
 def test_graph_replay_draws_fresh_dropout_masks():
     from mmidet_hip import fusion_ops as F2
     d = dev()

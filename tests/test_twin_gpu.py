@@ -302,6 +302,9 @@ def test_twin_model_equals_the_lane_form(kind, width):
         if pb.grad is None:
             assert pa.grad is None, k
             continue
+        if float(pb.grad.abs().max()) < 1e-7:              # analytically zero (the key bias of a softmax attention): rounding noise
+            assert float(pa.grad.abs().max()) < 1e-6, k
+            continue
         close(pa.grad, pb.grad, 2e-3, 'd(%s)' % k)      # two fp32 summation orders through the whole depth (cf. test_model_gpu)
         n_twin += 1
     assert n_twin > 100
