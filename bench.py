@@ -118,6 +118,10 @@ class ConvTimer:
         wrap('conv_dgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad', lambda a: fl(desc_of(a)))
         wrap('conv_wgrad_tab', lambda a: fl(desc_of(a)), 'conv_wgrad')
+        # twin launches (both backbones' copies of a layer in one launch: mmidet_hip/twin_ops.py): two problems of shape d
+        wrap('conv_bn_fwd2', lambda a: 2 * fl(desc_of(a)), 'conv_fwd')
+        wrap('conv_dgrad2', lambda a: 2 * fl(desc_of(a)), 'conv_dgrad')
+        wrap('conv_wgrad2', lambda a: 2 * fl(desc_of(a)), 'conv_wgrad')
         # the transformer blocks' Linear layers with fused epilogues (same kernels, counted with the convolutions)
         wrap('linear_fwd_fused', lambda a: fl(desc_of(a)), 'conv_fwd')
         wrap('linear_dgrad_fused', lambda a: fl(desc_of(a)), 'conv_dgrad')

@@ -200,6 +200,11 @@ class GradReducer:
                 if p.data_ptr() in self._ops.SLOT_HANDED_OUT:
                     raise RuntimeError('autograd copied a gradient that was written into its bucket view instead of '
                                        'adopting it (the copy may have read it before its wgrad stream finished)')
+                if self.cuda:
+                    # the gradient may have been produced on a wgrad side stream that the lane has not joined yet (deferred
+                    # join): order the copy behind every side stream in flight (rare path: a handful of small tensors)
+                    for sd in self._ops.side_streams_in_flight():
+                        cur.wait_stream(sd)
                 slot.copy_(p.grad)
                 p.grad = slot.detach()
         if not self.enabled:

@@ -178,6 +178,14 @@ def grad_like(t):
     if slot is not None and slot.shape == t.shape and slot.stride() == t.stride():
         SLOT_HANDED_OUT.add(t.data_ptr())
         return slot.detach()        # a fresh alias (sole owner), so that AccumulateGrad adopts it instead of cloning
+    if (slot is not None and t.dim() == 2 and slot.dim() == 4 and tuple(slot.shape) == (*t.shape, 1, 1) and t.is_contiguous()
+            and slot.is_contiguous(memory_format=torch.channels_last)):
+        # a 1x1 conv weight used as a matrix (GPT1_fourier's gates: `conv.weight.view(8, c)`): the same bytes in the same order,
+        # so the kernel writes the bucket view here too and the view's backward hands autograd an alias of it.  (Round 3: a
+        # fresh tensor here was copied into the slot by the reducer's hook on the LANE stream while its wgrad kernel was still
+        # running on the side stream -- deferred join -- which a captured step with wgrad overlap then exposed.)
+        SLOT_HANDED_OUT.add(t.data_ptr())
+        return slot.detach().as_strided(t.shape, t.stride())
     return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
 
 
