@@ -85,6 +85,23 @@ struct WgradP {
   const uint2* tab;
 };
 
+// Twin launches (two problems of one shape in one grid, blockIdx.z = problem): the kernels take ONE parameter block by value, as
+// they always did, plus the byte distances from problem 0's operands to problem 1's.  Problem 1's workgroups add them to their
+// copy of the pointers -- a handful of scalar adds behind a uniform branch.  (Selecting between two whole parameter blocks by
+// reference looked the same in the source but cost 2-4x the VALU instructions in the K loops -- the compiler no longer kept
+// the loaders' address parts scalar -- and with them 10-20 % of the dgrad / wgrad kernels' speed: profiles/r03_twin_param_select.txt.)
+struct IgemmDelta {
+  int64_t A, B, C, stat_part, sk_slots, sk_count, aux, aux_out, fold_part, fold_l1, fold_cnt, bn_mi, bn_rmean, bn_rvar, bn_nbt;
+};
+struct WgradDelta {
+  int64_t DY, X, OUT, OUTB, cnt, DW, DB;
+};
+template <typename T>
+__device__ __forceinline__ T* shift_ptr(T* p, int64_t bytes) {
+  return p == nullptr ? p : reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+}
+inline int64_t ptr_delta(const void* to, const void* from) { return (to == nullptr || from == nullptr) ? 0 : (int64_t)((const char*)to - (const char*)from); }
+
 struct FwdPlan {
   int bm, bn, mtiles, ntiles;   // per problem
   int sk_grid;  // > 0: stream-K schedule over this many workgroups (needs the workspace), 0: one workgroup per tile

@@ -195,10 +195,19 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // tile width, and skip the 32-column blocks beyond the last output column -- in the 2 x 2 layout half of the waves would own
 // nothing but padding and leave their SIMDs' matrix pipes idle.
 template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP prob0, IgemmP prob1) {
+__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p, IgemmDelta dz) {
   // twin launches (two problems of one shape, e.g. the RGB and IR backbone layers of the two-stream model): blockIdx.z picks the
-  // problem; a scalar select of the kernel-argument block, nothing per lane
-  const IgemmP& p = blockIdx.z ? prob1 : prob0;
+  // problem; problem 1 moves its copy of the operand pointers (igemm_defs.h::IgemmDelta), nothing per lane
+  if (blockIdx.z != 0) {  // uniform
+    p.A = shift_ptr(p.A, dz.A); p.B = shift_ptr(p.B, dz.B); p.C = shift_ptr(p.C, dz.C);
+    p.stat_part = shift_ptr(p.stat_part, dz.stat_part);
+    p.sk_slots = shift_ptr(p.sk_slots, dz.sk_slots); p.sk_count = shift_ptr(p.sk_count, dz.sk_count);
+    p.aux = shift_ptr(p.aux, dz.aux); p.aux_out = shift_ptr(p.aux_out, dz.aux_out);
+    p.bn_fold.part = shift_ptr(p.bn_fold.part, dz.fold_part); p.bn_fold.l1 = shift_ptr(p.bn_fold.l1, dz.fold_l1);
+    p.bn_fold.cnt = shift_ptr(p.bn_fold.cnt, dz.fold_cnt);
+    p.bn_mi = shift_ptr(p.bn_mi, dz.bn_mi); p.bn_rmean = shift_ptr(p.bn_rmean, dz.bn_rmean); p.bn_rvar = shift_ptr(p.bn_rvar, dz.bn_rvar);
+    p.bn_nbt = shift_ptr(p.bn_nbt, dz.bn_nbt);
+  }
   static_assert(!W41 || (DGRAD && !SK && PREC == 0 && !EPI && BM == 128), "the stacked wave layout exists for the plain fp32 dgrad tiles");
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");

@@ -57,12 +57,28 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   }
   // twin launch: a second problem of the same shape (other operand pointers, its own workspace) on gridDim.z = 2
   const int nz = twin != nullptr ? 2 : 1;
-  IgemmP q = twin != nullptr ? *twin : p;
-  if (q.mi_stride == 0) q.mi_stride = q.Ncol;
-  q.zero = p.zero; q.mtiles = p.mtiles; q.ntiles = p.ntiles; q.a_bytes = p.a_bytes; q.b_bytes = p.b_bytes; q.c_bytes = p.c_bytes;
+  IgemmDelta q{};   // byte distances to the twin problem's operands (everything else is shared: same shape, same schedule)
+  if (twin != nullptr) {
+    const IgemmP& t = *twin;
+    if (t.bias != nullptr || p.bias != nullptr || t.res != nullptr || p.res != nullptr || (t.bn_mi == nullptr) != (p.bn_mi == nullptr) ||
+        (t.stat_part == nullptr) != (p.stat_part == nullptr) || (t.aux == nullptr) != (p.aux == nullptr) || t.epi != p.epi ||
+        t.ldaux != p.ldaux || (t.mi_stride != 0 && t.mi_stride != p.mi_stride) || t.bn_nnbt != p.bn_nnbt ||
+        (t.bn_rmean == nullptr) != (p.bn_rmean == nullptr)) {
+      mmi_set_error("%s: the two problems of a twin launch must agree in everything but their operand addresses", who);
+      return MMI_ERR_ARG;
+    }
+    q.A = ptr_delta(t.A, p.A); q.B = ptr_delta(t.B, p.B); q.C = ptr_delta(t.C, p.C);
+    q.stat_part = ptr_delta(t.stat_part, p.stat_part);
+    q.aux = ptr_delta(t.aux, p.aux); q.aux_out = ptr_delta(t.aux_out, p.aux_out);
+    q.fold_part = ptr_delta(t.bn_fold.part, p.bn_fold.part); q.fold_l1 = ptr_delta(t.bn_fold.l1, p.bn_fold.l1);
+    q.fold_cnt = ptr_delta(t.bn_fold.cnt, p.bn_fold.cnt);
+    q.bn_mi = ptr_delta(t.bn_mi, p.bn_mi); q.bn_rmean = ptr_delta(t.bn_rmean, p.bn_rmean); q.bn_rvar = ptr_delta(t.bn_rvar, p.bn_rvar);
+    q.bn_nbt = ptr_delta(t.bn_nbt, p.bn_nbt);
+    q.sk_slots = ptr_delta(t.sk_slots, p.sk_slots); q.sk_count = ptr_delta(t.sk_count, p.sk_count);
+  }
   if (f.sk_grid > 0) {
     if (twin != nullptr) {   // (the caller laid out both problems' counters and slots: igemm.hip, "twin launches")
-      if (p.sk_count == nullptr || p.sk_slots == nullptr || q.sk_count == nullptr || q.sk_slots == nullptr) {
+      if (p.sk_count == nullptr || p.sk_slots == nullptr || twin->sk_count == nullptr || twin->sk_slots == nullptr) {
         mmi_set_error("%s: a twin launch of a stream-K shape needs both problems' workspaces", who);
         return MMI_ERR_WORKSPACE;
       }
@@ -162,7 +178,7 @@ int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who
   p.mtiles = f.mtiles;
   p.ntiles = f.ntiles;
   if (p.mi_stride == 0) p.mi_stride = p.Ncol;
-  const IgemmP& q = p;   // (single problem)
+  const IgemmDelta q{};   // (single problem)
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
   if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
   else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);

@@ -25,8 +25,11 @@ namespace {
 // a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
 // resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
 template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
-__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP prob0, WgradP prob1) {
-  const WgradP& p = blockIdx.z ? prob1 : prob0;   // twin launches: blockIdx.z = problem (see igemm_kernel)
+__global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP p, WgradDelta dz) {
+  if (blockIdx.z != 0) {  // twin launches: blockIdx.z = problem (see igemm_kernel); uniform
+    p.DY = shift_ptr(p.DY, dz.DY); p.X = shift_ptr(p.X, dz.X); p.OUT = shift_ptr(p.OUT, dz.OUT); p.OUTB = shift_ptr(p.OUTB, dz.OUTB);
+    p.cnt = shift_ptr(p.cnt, dz.cnt); p.DW = shift_ptr(p.DW, dz.DW); p.DB = shift_ptr(p.DB, dz.DB);
+  }
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
@@ -864,7 +867,12 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
     }
   }
   const WgradP& p = pp[0];
-  const WgradP& q = pp[nprob - 1];
+  WgradDelta q{};
+  if (nprob > 1) {
+    const WgradP& t = pp[1];
+    q.DY = ptr_delta(t.DY, p.DY); q.X = ptr_delta(t.X, p.X); q.OUT = ptr_delta(t.OUT, p.OUT); q.OUTB = ptr_delta(t.OUTB, p.OUTB);
+    q.cnt = ptr_delta(t.cnt, p.cnt); q.DW = ptr_delta(t.DW, p.DW); q.DB = ptr_delta(t.DB, p.DB);
+  }
   const dim3 grid(g.mtiles * g.ntiles, g.splits, nprob), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
