@@ -258,7 +258,12 @@ class Model(nn.Module):
         self.ContrastiveValue = self.SSIMloss = self.PTLoss = self.Entropy_loss = empty
         x = ops.nchw_to_nhwc(x)
         x2 = ops.nchw_to_nhwc(x2)
-        bf16 = getattr(self, 'storage', 'f32') == 'bf16'
+        # AMP (train.py:706,784 of the reference: fp16 autocast + GradScaler).  The kernels compute in fp32 whatever the autocast
+        # context says, so the reference's loop runs the exact path unchanged (tests/test_reference_loop_gpu.py).  The MI355X
+        # counterpart of its reduced-precision mode is bf16 STORAGE of the activation maps (same exponent range as
+        # fp32, no loss scaling needed, a GradScaler around it is harmless); MMIDET_AMP=bf16 maps an active autocast context to it.
+        bf16 = getattr(self, 'storage', 'f32') == 'bf16' or (os.environ.get('MMIDET_AMP', '') == 'bf16' and x.is_cuda
+                                                             and torch.is_autocast_enabled())
         # Twin launches (mmidet_hip/twin_ops.py): every layer pair of the two backbones runs as one set of launches over a twin
         # tensor, on the caller's stream.  Layers outside a pair (and every layer when MMIDET_TWIN=0, in the bf16 storage mode or
         # after fuse()) take the lane form: the IR backbone on its own HIP stream, events at every cross-lane hand-off.

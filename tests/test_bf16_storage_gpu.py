@@ -157,6 +157,49 @@ def test_graph_bf16_storage_tracks_fp32(kind, bn):
         assert coss[len(coss) // 2] > 0.6, (coss[len(coss) // 2], coss[:3])
 
 
+def test_autocast_selects_the_bf16_storage_mode_when_asked(monkeypatch):
+    """f-4: the reference switches its reduced-precision mode with `amp.autocast(enabled=cuda)` + GradScaler (train.py:706,784,
+    796).  By default an autocast context changes nothing here (tests/test_reference_loop_gpu.py); with MMIDET_AMP=bf16 an active
+    context selects the bf16 storage mode for that forward -- the same launches as Model.storage = 'bf16', bit for bit -- and a
+    GradScaler around it scales and unscales exactly (a power of two in a format with fp32's exponent range)."""
+    from test_model_gpu import build_pair
+    from oracle import portable_init
+    from utils.loss import ComputeLoss
+    m_a, _, cfg = build_pair('fourier', 128)
+    m_b = copy.deepcopy(m_a)
+    m_b.storage = 'bf16'
+    imgs, targets = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=12)
+    x = (imgs.float() / 255).to(dev())
+    monkeypatch.setenv('MMIDET_AMP', 'bf16')
+    scaler = torch.amp.GradScaler('cuda')
+    m_a.train()
+    with torch.amp.autocast('cuda'):
+        p, c = m_a(x[:, :3], x[:, 3:])
+        loss_a, _ = ComputeLoss(m_a)(p, targets.to(dev()), c.reshape(-1))
+    scaler.scale(loss_a).backward()
+    monkeypatch.delenv('MMIDET_AMP')
+    m_b.train()
+    p, c = m_b(x[:, :3], x[:, 3:])
+    loss_b, _ = ComputeLoss(m_b)(p, targets.to(dev()), c.reshape(-1))
+    loss_b.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_a, loss_b)
+    inv = 1.0 / scaler.get_scale()
+    worst = 0.0
+    for (n, pa), pb in zip(m_a.named_parameters(), m_b.parameters()):
+        if pb.grad is None:
+            continue
+        worst = max(worst, rel_err(pa.grad * inv, pb.grad))
+    assert worst < 1e-6, worst          # (exact up to the bf16 rounding of activation GRADIENTS, which the scale shifts by 16 binades: none)
+    # and without the switch the same context leaves the fp32 path alone
+    m_c = copy.deepcopy(m_b)
+    m_c.storage = 'f32'
+    m_c.zero_grad(set_to_none=True)
+    with torch.amp.autocast('cuda'):
+        p, c = m_c(x[:, :3], x[:, 3:])
+    assert p[0].dtype == torch.float32 and not torch.equal(p[0], torch.zeros_like(p[0]))
+
+
 def test_bf16x1_gemm_mode_on_fp32_operands():
     """mmi_set_gemm_precision(5): fp32 tensors in HBM, every operand rounded to one bf16 term when staged, one bf16 MFMA product,
     fp32 accumulation -- the arithmetic the storage mode gives the GEMMs whose operands stay fp32 (token Linear layers)."""
