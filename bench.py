@@ -306,11 +306,13 @@ def main():
                                                        'feeder (mmidet_hip.feed): the PCIe-inclusive rate, reported beside `value`')
     ap.add_argument('--mode', default='auto', choices=['auto', 'graph', 'eager'], help='launch mode (see main)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
+    ap.add_argument('--spawn', action='store_true', help='start the rank(s) through torch.distributed.run even for one GPU: rehearses '
+                                                         'the launcher path `--gpus N` takes for N > 1 (tests/test_bench_contract_gpu.py)')
     args = ap.parse_args()
     if args.storage == 'bf16':          # (the roofline pass and the split-bf16 probe describe the fp32 kernels)
         args.no_roofline = args.no_split_probe = True
 
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or args.spawn) and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU ourselves.  This parent never touches the GPU
         # (nothing above initialises HIP); the ranks are fresh child processes and rank 0's JSON line is relayed as is.
         import socket
@@ -319,7 +321,7 @@ def main():
             sk.bind(('127.0.0.1', 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--spawn']
         env = dict(os.environ)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', '2')
@@ -551,6 +553,8 @@ def main():
                        'batch_per_gpu': bs, 'global_batch': bs * world, 'image': '2x(3,%d,%d)' % (size, size), 'dropout_p': args.dropout,
                        'step': 'fwd+loss+bwd+allreduce+SGD(nesterov)+EMA', 'parallelism': 'dp%d' % world,
                        'launch_mode_probe_ms': probes,
+                       'backbone_launch_form': ('twin launches (both backbones\' layer pairs in one grid)' if getattr(model, 'twin', False) and args.storage == 'f32'
+                                                else 'two lanes (RGB / IR backbone on two HIP streams)'),
                        'launch_mode': ('eager, wgrad on a side stream' if not use_graph else 'whole-step hipGraph replay' if not ddp else
                                        'whole-step hipGraph replay incl. the RCCL bucket all-reduces' if comm_kind == 'native' else
                                        'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),

@@ -43,3 +43,19 @@ def test_long_unsynchronised_run_stays_finite():
     loss = j['config']['loss']
     assert all(v == v and abs(v) < 1e3 for v in loss), loss           # finite (bench asserts it too) and sane
     assert loss[3] < 0.25, loss                                       # the detection loss has come down from ~0.32 / image
+
+
+def test_self_spawned_rank_with_the_native_transport_world1():
+    """`python bench.py --gpus N` starts its own ranks (torch.distributed.run, before anything touches the GPU) and relays rank
+    0's JSON line: the launcher path of the N > 1 runs, rehearsed at world size 1 with the library's own RCCL communicator
+    (MMIDET_COMM=native) and the data-parallel code path (--ddp)."""
+    env = dict(os.environ, MMIDET_COMM='native')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--spawn', '--ddp', '--workload', 's_add',
+                        '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--no-roofline', '--no-split-probe'],
+                       capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and 'mmi_allreduce_bucket' in (j['config']['gradient_transport'] or '')
+    assert j['value'] > 0 and all(v == v for v in j['config']['loss'])
