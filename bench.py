@@ -574,14 +574,16 @@ def main():
             # this very command, tools/pmc_step.sh) and committed under profiles/; reported only for the workload it was taken on
             traffic = None
             try:
-                with open(os.path.join(REPO, 'profiles', 'r02_pmc_step_traffic.json')) as fh:
+                import glob
+                pmc_file = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_step_traffic.json')))[-1]   # the latest round's record
+                with open(pmc_file) as fh:
                     pt = json.load(fh)
                 if pt.get('workload') == args.workload and bs == WORKLOADS[args.workload][5]:
                     traffic = {'read_MB_per_step': pt['read_MB_per_step'].get('igemm'), 'write_MB_per_step': pt['write_MB_per_step'].get('igemm'),
                                'unit': 'MB of HBM/fabric traffic of the igemm family per training step (PMC: FETCH_SIZE x2 + WRITE_SIZE)',
                                'all_families_MB_per_step': pt.get('total_MB_per_step'),
-                               'source': 'profiles/r02_pmc_step_traffic.json (tools/pmc_step.sh)'}
-            except (OSError, ValueError, KeyError):
+                               'source': 'profiles/%s (tools/pmc_step.sh)' % os.path.basename(pmc_file)}
+            except (OSError, ValueError, KeyError, IndexError):
                 pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
