@@ -279,6 +279,8 @@ int mmi_add(const float* a, int lda, const float* b, int ldb, float* out, int ld
 int mmi_copy2d(const float* in, int ldi, float* out, int ldo, int64_t rows, int C, void* stream);
 /* nearest x2 upsample (nn.Upsample in the YAML head) and its backward (sum of the 4 children) */
 int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* the same on rows with strides: x and / or y may be channel slices of wider buffers (the neck's concat buffers) */
+int mmi_upsample2x_ld(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, void* stream);
 int mmi_upsample2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* the same with dy read through a row stride (a channel slice of a Concat gradient) and, when skip != NULL, the gradient of
  * the map's OTHER consumer added in the same pass: dx = sum4(dy) + skip.  Replaces the autograd engine's fan-out accumulation
@@ -383,7 +385,9 @@ int mmi_build_targets(const float* targets, int nt, const float* anchors, int nl
  * preds/dpreds: HOST arrays of nl device pointers to (bs,na,ny,nx,nc+5) tensors; grids_host[nl][2]=(ny,nx) and
  * balance_host[nl] are host arrays; idx/tcls/tbox/anch/counts/cap are mmi_build_targets outputs (device).  combine:
  * device vector of ncombine CombineLoss values (may be NULL when ncombine=0).  out5 = (loss*bs, lbox, lobj, lcls,
- * Detectloss).  dpreds receive d(out5[0])/d(preds). */
+ * Detectloss).  dpreds receive d(out5[0])/d(preds).  flag: bit 0 = add the CombineLoss term (the reference's `Flag`); bit 1 = the
+ * tensors are the head convolutions' NHWC outputs (bs,ny,nx,na*(nc+5)), i.e. Detect's (bs,na,ny,nx,nc+5) result as a strided
+ * view of them (models/yolo_test.py:54-55 without the permute copy); dpreds take the same layout. */
 size_t mmi_detect_loss_workspace(int nl, int64_t total_cells, int64_t cap);
 int mmi_detect_loss(const float* const* preds, float* const* dpreds, const int32_t* grids_host, int nl, int bs, int na,
                     int nc, const int64_t* idx, const int64_t* tcls, const float* tbox, const float* anch,

@@ -94,7 +94,7 @@ __global__ void copy2d_kernel(const float* __restrict__ a, int lda, float* __res
 }
 
 template <int V>
-__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+__global__ void upsample2x_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N, int H, int W, int C) {
   const int cv = C / V, Ho = 2 * H, Wo = 2 * W;
   const int64_t total = (int64_t)N * Ho * Wo * cv;
   GRID_STRIDE(e, total) {
@@ -104,8 +104,8 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
     t /= Wo;
     const int oh = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    const float* src = x + (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * C + c;
-    float* dst = y + (((int64_t)n * Ho + oh) * Wo + ow) * C + c;
+    const float* src = x + (((int64_t)n * H + (oh >> 1)) * W + (ow >> 1)) * ldx + c;
+    float* dst = y + (((int64_t)n * Ho + oh) * Wo + ow) * ldy + c;
     if (V == 4) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
     else dst[0] = src[0];
   }
@@ -392,16 +392,20 @@ extern "C" int mmi_copy2d(const float* in, int ldi, float* out, int ldo, int64_t
   return MMI_OK;
 }
 
-extern "C" int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int C, void* stream) {
-  MMI_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "mmi_upsample2x: bad arguments");
-  if (vec4(C, {}, {x, y}))
-    hipLaunchKernelGGL(upsample2x_kernel<4>, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x,
-                       y, N, H, W, C);
+// x rows with stride ldx, y rows with stride ldy: either may be a channel slice of a wider buffer (the neck's concat buffers)
+extern "C" int mmi_upsample2x_ld(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, void* stream) {
+  MMI_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && ldy >= C, "mmi_upsample2x: bad arguments");
+  if (vec4(C, {ldx, ldy}, {x, y}))
+    hipLaunchKernelGGL(upsample2x_kernel<4>, dim3(ew_blocks((int64_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       y, ldy, N, H, W, C);
   else
     hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(ew_blocks((int64_t)N * H * W * C * 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, N, H, W, C);
+                       (hipStream_t)stream, x, ldx, y, ldy, N, H, W, C);
   MMI_CHECK_LAUNCH("mmi_upsample2x");
   return MMI_OK;
+}
+extern "C" int mmi_upsample2x(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  return mmi_upsample2x_ld(x, C, y, C, N, H, W, C, stream);
 }
 
 extern "C" int mmi_upsample2x_bwd_acc(const float* dy, int lddy, const float* skip, int ldskip, float* dx, int N, int H, int W, int C,

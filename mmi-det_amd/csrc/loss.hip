@@ -30,7 +30,22 @@ struct LossP {
   float* grec;             // (nl,cap,no) gradient contribution of every record (slot 4 unused)
   int nl, na, no, nc, cap, bs;
   float hbox, hobj, hcls, gr, cp, cn;
+  // nhwc = 1: p / dp are the head convolutions' own NHWC outputs (B,ny,nx,na*no) -- Detect's (B,na,ny,nx,no) tensor as a strided
+  // view of them (models/yolo_test.py:54-55 of the reference without the permute copy); cells are still numbered anchor-major
+  int nhwc;
 };
+// element offset of the outputs of the cell with anchor-major number `cell` = ((b*na + a)*ny + gj)*nx + gi
+__device__ __forceinline__ int64_t pred_off(const LossP& P, int l, int64_t cell) {
+  if (!P.nhwc) return cell * P.no;
+  const int nx = P.nx[l], ny = P.ny[l];
+  const int gi = (int)(cell % nx);
+  int64_t t = cell / nx;
+  const int gj = (int)(t % ny);
+  t /= ny;
+  const int a = (int)(t % P.na);
+  const int64_t b = t / P.na;
+  return (((b * ny + gj) * nx + gi) * P.na + a) * P.no;
+}
 
 // forward-mode dual number over the 4 predicted box parameters (x, y, w, h)
 struct D4 {
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256) void loss_records_kernel(LossP P) {
     const int64_t* ix = P.idx + (int64_t)l * 4 * P.cap;
     const int b = (int)ix[r], a = (int)ix[P.cap + r], gj = (int)ix[2 * (int64_t)P.cap + r], gi = (int)ix[3 * (int64_t)P.cap + r];
     const int64_t cell = (((int64_t)b * P.na + a) * P.ny[l] + gj) * P.nx[l] + gi;
-    const float* ps = P.p[l] + cell * no;
+    const float* ps = P.p[l] + pred_off(P, l, cell);
     const float* an = P.anch + ((int64_t)l * P.cap + r) * 2;
     const float s0 = sigm(ps[0]), s1 = sigm(ps[1]), s2 = sigm(ps[2]), s3 = sigm(ps[3]);
     const float px = s0 * 2.f - 0.5f, py = s1 * 2.f - 0.5f;                 // loss.py:128
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void loss_scatter_kernel(LossP P) {
   for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
     const int cell = cid[r];
     if (P.owner[l][cell] != r) continue;
-    float* dps = P.dp[l] + (int64_t)cell * no;
+    float* dps = P.dp[l] + pred_off(P, l, cell);
     if (P.cnt[l][cell] == 1) {
       for (int k = 0; k < no; ++k)
         if (k != 4) dps[k] = g[(int64_t)r * no + k];
@@ -210,12 +225,13 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossP P) {
   const float g = (float)P.bs * P.hobj * P.balance[l] / (float)ncell;
   double s = 0.0;
   for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < ncell; c += (int64_t)gridDim.x * 256) {
-    const float x = P.p[l][c * no + 4];
+    const int64_t po = pred_off(P, l, c);
+    const float x = P.p[l][po + 4];
     const int o = P.owner[l][c];
     float t = 0.f;
     if (o >= 0) t = (1.0f - P.gr) + P.gr * fmaxf(P.iou[(int64_t)l * P.cap + o], 0.f);   // loss.py:135
     s += (double)bce_logits(x, t);
-    P.dp[l][c * no + 4] = g * (sigm(x) - t);
+    P.dp[l][po + 4] = g * (sigm(x) - t);
   }
   block_sum_to(s, P.acc + (int64_t)l * ACC_STRIDE + 2 * REC_BLOCKS + blockIdx.x, sh);
 }
@@ -317,6 +333,8 @@ extern "C" int mmi_detect_loss(const float* const* preds, float* const* dpreds, 
   P.idx = idx; P.tcls = tcls; P.tbox = tbox; P.anch = anch; P.counts = counts;
   P.nl = nl; P.na = na; P.no = nc + 5; P.nc = nc; P.cap = (int)cap; P.bs = bs;
   P.hbox = hbox; P.hobj = hobj; P.hcls = hcls; P.gr = gr; P.cp = cp; P.cn = cn;
+  P.nhwc = (flag & 2) ? 1 : 0;
+  flag &= 1;
   if (cap > 0) {
     const dim3 rgrid(cdiv(cap, 256) > REC_BLOCKS ? REC_BLOCKS : cdiv(cap, 256), nl);
     hipLaunchKernelGGL(loss_records_kernel, rgrid, dim3(256), 0, s, P);

@@ -111,6 +111,7 @@ _SIGS = {
     'mmi_add': (c_int, [P, c_int, P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_copy2d': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
     'mmi_upsample2x': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'mmi_upsample2x_ld': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample2x_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'mmi_upsample2x_bwd_acc': (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'mmi_spp_pool_fwd': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -586,6 +586,34 @@ def cat_alias(a, b, holder):
     return _CatAlias.apply(a, b, holder)
 
 
+class _CatAliasN(Function):
+    """Concat of tensors that already ARE consecutive channel slices of one buffer (the neck's Concat layers, whose producers
+    wrote into the buffer: models/common.py:740-748 of the reference without the copy)."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        cat = holder.t
+        off, es = 0, cat.element_size()
+        for x in xs:
+            assert x.data_ptr() == cat.data_ptr() + es * off and x.shape[:-1] == cat.shape[:-1], 'cat_alias: an input is not its slice of the buffer'
+            off += x.shape[-1]
+        assert off == cat.shape[-1]
+        ctx.sizes = [x.shape[-1] for x in xs]
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.sizes:
+            outs.append(g[..., off:off + c])
+            off += c
+        return (None, *outs)
+
+
+def cat_alias_n(xs, holder):
+    return _CatAliasN.apply(holder, *xs)
+
+
 def pack_pair(model):
     """Re-seat cv1 / cv2 of every C3 (conv weights, BatchNorm weight / bias / running statistics / num_batches_tracked) on
     shared buffers, cv1's part first: same Parameters, same state_dict keys and values, but the two 1x1 convolutions over the
@@ -748,23 +776,25 @@ def linear(x, w, bias=None):
 
 
 class _Add(Function):
+    """a + b; dest=(Dest, channel): write the sum into that channel slice of a wider buffer (a neck Concat's buffer)."""
+
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, dest):
         a, lda = rows_of(a)
         b, ldb = rows_of(b)
-        out = torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
+        out = _dest_view(dest, a.shape) if dest is not None else torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
         c = a.shape[-1]
-        assert a.dtype == b.dtype
-        (lib.add_bf16 if a.dtype == BF16 else lib.add)(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), c, _nrows(a), c, _stream())
+        assert a.dtype == b.dtype == out.dtype
+        (lib.add_bf16 if a.dtype == BF16 else lib.add)(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), rows_of(out)[1], _nrows(a), c, _stream())
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, g
+        return g, g, None
 
 
-def add(a, b):
-    return _Add.apply(a, b)
+def add(a, b, dest=None):
+    return _Add.apply(a, b, dest)
 
 
 class _Concat(Function):
@@ -805,15 +835,20 @@ class _Upsample2x(Function):
     engine (an ATen add); the incoming gradient is read through its row stride (a channel slice of a Concat gradient)."""
 
     @staticmethod
-    def forward(ctx, x, skip):
+    def forward(ctx, x, skip, dest):
         ctx.set_materialize_grads(False)
         x_in = x
         x, ld = rows_of(x)
-        if ld != x.shape[-1]:
-            x = x.contiguous()
         n, h, w, c = x.shape
-        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
-        (lib.upsample2x_bf16 if x.dtype == BF16 else lib.upsample2x)(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
+        if x.dtype == BF16:
+            assert dest is None
+            if ld != c:
+                x = x.contiguous()
+            y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+            lib.upsample2x_bf16(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
+        else:      # rows with strides on both sides: the input may be a slice of a Concat buffer, the output written into one
+            y = _dest_view(dest, (n, 2 * h, 2 * w, c)) if dest is not None else torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+            lib.upsample2x_ld(x.data_ptr(), ld, y.data_ptr(), rows_of(y)[1], n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
         return (y, x_in) if skip else y
 
@@ -821,7 +856,7 @@ class _Upsample2x(Function):
     def backward(ctx, g, gskip=None):
         n, h, w, c = ctx.shape
         if g is None:
-            return gskip, None
+            return gskip, None, None
         dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
         if g.dtype == BF16:
             g = g.contiguous()
@@ -829,15 +864,15 @@ class _Upsample2x(Function):
             if gskip is not None:
                 gs, lds = rows_of(raw_cast(gskip, BF16))
                 lib.add_bf16(dx.data_ptr(), c, gs.data_ptr(), lds, dx.data_ptr(), c, _nrows(dx), c, _stream())
-            return dx, None
+            return dx, None, None
         g, ldg = rows_of(g)
         gs, lds = rows_of(gskip) if gskip is not None else (None, 0)
         lib.upsample2x_bwd_acc(g.data_ptr(), ldg, gs.data_ptr() if gs is not None else None, lds, dx.data_ptr(), n, h, w, c, _stream())
-        return dx, None
+        return dx, None, None
 
 
-def upsample2x(x, skip=False):
-    return _Upsample2x.apply(x, skip)
+def upsample2x(x, skip=False, dest=None):
+    return _Upsample2x.apply(x, skip, dest)
 
 
 class _SppPool(Function):

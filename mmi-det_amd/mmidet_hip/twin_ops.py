@@ -462,21 +462,22 @@ class _TwinAddLanes(Function):
     gradient of both lanes is the incoming gradient itself: returned as a stride-0 twin view, no copy."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dest):
         ld, ls = layout(x)
         n, h, w, _, c = x.shape
-        out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
-        lib.add(x.data_ptr(), ld, x.data_ptr() + 4 * ls, ld, out.data_ptr(), c, n * h * w, c, _stream())
+        out = ops._dest_view(dest, (n, h, w, c)) if dest is not None else torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        lib.add(x.data_ptr(), ld, x.data_ptr() + 4 * ls, ld, out.data_ptr(), ops.rows_of(out)[1], n * h * w, c, _stream())
         return out
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        return g.unsqueeze(3).expand(-1, -1, -1, 2, -1)
+        g, ldg = ops.rows_of(g)
+        n, h, w, c = g.shape
+        return g.as_strided((n, h, w, 2, c), (h * w * ldg, w * ldg, ldg, 0, 1)), None      # both lanes: the same rows, no copy
 
 
-def add_lanes(x):
-    return _TwinAddLanes.apply(x)
+def add_lanes(x, dest=None):
+    return _TwinAddLanes.apply(x, dest)
 
 
 class _TwinStack(Function):

@@ -207,7 +207,11 @@ class Concat(nn.Module):
         super().__init__()
         self.d = dimension  # NCHW dim 1 == the contiguous channel axis of the NHWC activations
 
-    def forward(self, x):
+    def forward(self, x, holder=None):
+        """holder (ops.Dest): the inputs already are the channel slices of this buffer, written there by their producers
+        (Model._plan_concats): nothing to copy."""
+        if holder is not None:
+            return ops.cat_alias_n(list(x), holder)
         return ops.concat(list(x))
 
 
@@ -216,11 +220,11 @@ class Add(nn.Module):
         super().__init__()
         self.arg = arg
 
-    def forward(self, x):
-        return ops.add(x[0], x[1])
+    def forward(self, x, dest=None):
+        return ops.add(x[0], x[1], dest)
 
-    def twin(self, x):
-        return T2.add_lanes(x)
+    def twin(self, x, dest=None):
+        return T2.add_lanes(x, dest)
 
 
 class FusedTokens:

@@ -53,9 +53,9 @@ class Upsample2x(nn.Upsample):
 
     fan_skip = True
 
-    def forward(self, x, skip=False):
+    def forward(self, x, skip=False, dest=None):
         assert self.mode == 'nearest' and float(self.scale_factor) == 2.0
-        return ops.upsample2x(x, skip)
+        return ops.upsample2x(x, skip, dest)
 
 
 class Detect(nn.Module):
@@ -77,7 +77,13 @@ class Detect(nn.Module):
         self.training |= self.export
         for i in range(self.nl):
             y = ops.conv_bias(x[i], self.m[i].weight, self.m[i].bias, 1)         # (B,ny,nx,na*no)
-            x[i] = ops.head_permute(y, self.na)                                   # (B,na,ny,nx,no)
+            if self.training and os.environ.get('MMIDET_HEAD_VIEW', '1') != '0':
+                # the NHWC output of the 1x1 conv IS the permuted layout: (B,na,ny,nx,no) as a strided view, no copy either way
+                # (the loss kernels read it in place: utils/loss.py; models/yolo_test.py:54-55 of the reference copies here)
+                b, ny, nx, _ = y.shape
+                x[i] = y.view(b, ny, nx, self.na, self.no).permute(0, 3, 1, 2, 4)
+            else:
+                x[i] = ops.head_permute(y, self.na)                               # (B,na,ny,nx,no) contiguous
         if self.training:
             return x
         # eval (models/yolo_test.py:57-68): sigmoid + grid/anchor decode of every level straight into the cat buffer
@@ -163,6 +169,43 @@ class Model(nn.Module):
                 if isinstance(first.f, int) or isinstance(first, GPT):
                     self._fan_skip.setdefault(c[0], []).append(j)
         self._plan_twins(cons)
+        self._plan_concats(cons)
+
+    def _plan_concats(self, cons):
+        """Neck Concat layers without the copy (models/common.py:740-748 of the reference): when every input of a Concat comes
+        from a layer that can write into a channel slice of a wider buffer (Conv, the nearest up-sampling, Add) and feeds no other
+        Concat, the producers write straight into the Concat's buffer and the Concat itself is an alias.
+        _cat_plan[producer] = (concat layer, channel offset); _cat_total[concat layer] = channels of its buffer."""
+        self._cat_plan, self._cat_total = {}, {}
+        if os.environ.get('MMIDET_CAT_DEST', '1') == '0':
+            return
+        cout = {}
+        for m in self.model:          # static output channel counts of the layers that matter here
+            src = self._srcs[m.i]
+            if isinstance(m, Conv):
+                cout[m.i] = m.conv.weight.shape[0]
+            elif isinstance(m, (C3, SPP)):
+                cout[m.i] = (m.cv3 if isinstance(m, C3) else m.cv2).conv.weight.shape[0]
+            elif isinstance(m, Focus):
+                cout[m.i] = m.conv.conv.weight.shape[0]
+            elif isinstance(m, (Add, Add2, Upsample2x)) and src and src[0] in cout:
+                cout[m.i] = cout[src[0]]
+            elif isinstance(m, Concat) and all(j in cout for j in src):
+                cout[m.i] = sum(cout[j] for j in src)
+        for m in self.model:
+            if not isinstance(m, Concat):
+                continue
+            src = self._srcs[m.i]
+            ok = len(src) >= 2 and len(set(src)) == len(src) and all(
+                j in cout and isinstance(self.model[j], (Conv, Add, Upsample2x)) and j not in self._cat_plan
+                and j not in self._leader_of and j not in self._follower_of
+                and sum(1 for c in cons.get(j, []) if isinstance(self.model[c], Concat)) == 1 for j in src)
+            if ok:
+                off = 0
+                for j in src:
+                    self._cat_plan[j] = (m.i, off)
+                    off += cout[j]
+                self._cat_total[m.i] = off
 
     def _plan_twins(self, cons):
         """Twin plan: pair every IR-backbone layer (follower) with the RGB-backbone layer (leader) that is the same module on the
@@ -212,7 +255,7 @@ class Model(nn.Module):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        if '_lanes' not in state or '_fan_skip' not in state or '_leader_of' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
+        if '_lanes' not in state or '_fan_skip' not in state or '_leader_of' not in state or '_cat_plan' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
             self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
             self._plan_lanes()
 
@@ -298,6 +341,27 @@ class Model(nn.Module):
                 return x2
             return y[m.f] if isinstance(m.f, int) else [prev if j == -1 else y[j] for j in m.f]
 
+        use_cat = bool(self._cat_plan) and not bf16 and x.is_cuda
+        cat_bufs = {}                                              # Concat layer -> ops.Dest holding its buffer
+
+        def cat_dest(m, xin):
+            """(Dest, channel offset) when layer m writes into a neck Concat's buffer (_plan_concats), else None."""
+            plan = self._cat_plan.get(m.i) if use_cat else None
+            if plan is None:
+                return None
+            k, off = plan
+            holder = cat_bufs.get(k)
+            if holder is None:
+                t = xin[0] if isinstance(xin, (list, tuple)) else xin
+                n, h, w = t.shape[:3]
+                if isinstance(m, Conv):
+                    ks, st = m.conv.kernel_size[0], m.conv.stride[0]
+                    h, w = (h + 2 * (ks // 2) - ks) // st + 1, (w + 2 * (ks // 2) - ks) // st + 1
+                elif isinstance(m, Upsample2x):
+                    h, w = 2 * h, 2 * w
+                holder = cat_bufs[k] = ops.Dest(torch.empty((n, h, w, self._cat_total[k]), dtype=torch.float32, device=dev))
+            return (holder, off)
+
         def twin_of(v):
             """The twin tensor behind a pair of inputs [Lane(L,0), Lane(L,1)] of one pair's output, else None."""
             if (isinstance(v, (list, tuple)) and len(v) == 2 and isinstance(v[0], Lane) and isinstance(v[1], Lane)
@@ -361,7 +425,7 @@ class Model(nn.Module):
                 y.append(x if i in self.save else None)
                 continue
             if lead is not None and isinstance(m, Add):
-                prev = x = m.twin(tw[lead])
+                prev = x = m.twin(tw[lead], dest=cat_dest(m, tw[lead]))
                 y.append(x if i in self.save else None)
                 continue
             from_twin = twin and any(isinstance(v, Lane) for v in (xin if isinstance(xin, (list, tuple)) else [xin]))
@@ -396,15 +460,21 @@ class Model(nn.Module):
                     st = F2.fusion_stats(in_rgb, in_ir, m.last_tokens)
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
+                kw = {}
+                if isinstance(m, Concat):
+                    if i in cat_bufs:                              # every input already is its slice of the buffer
+                        kw['holder'] = cat_bufs.pop(i)
+                elif use_cat and i in self._cat_plan:
+                    kw['dest'] = cat_dest(m, x)
                 if i in fan and not any(isinstance(y[k], Lane) for k in self._srcs[i]):   # (output, alias of the input for its second consumer)
-                    x, alias = m(x, skip=True)
+                    x, alias = m(x, skip=True, **kw)
                     if isinstance(alias, (list, tuple)):
                         for k, a in zip(self._srcs[i], alias):
                             y[k] = a
                     else:
                         y[self._srcs[i][0]] = alias
                 else:
-                    x = m(x)
+                    x = m(x, **kw)
                 if bf16 and i == 0:
                     x = ops.cast(x, torch.bfloat16)          # behind the RGB stem (Focus): everything downstream is bf16
             if lanes:
@@ -466,6 +536,7 @@ class Model(nn.Module):
                 m.forward = m.fuseforward
         self._fan_skip = {}                                        # (fuseforward has no hand-on form; inference does not need one)
         self._twin_fan, self.twin = {}, False
+        self._cat_plan, self._cat_total = {}, {}                   # (fuseforward has no destination form either)
         self.info()
         return self
 

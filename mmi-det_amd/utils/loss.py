@@ -22,12 +22,24 @@ def smooth_BCE(eps=0.1):
     return 1.0 - 0.5 * eps, 0.5 * eps
 
 
+def _is_head_view(p):
+    """(B,na,ny,nx,no) as the permuted view of a dense NHWC (B,ny,nx,na*no) tensor (Detect.forward in training mode)."""
+    if p.dim() != 5:
+        return False
+    b, na, ny, nx, no = p.shape
+    return p.stride() == (ny * nx * na * no, no, nx * na * no, na * no, 1)
+
+
 class _DetectLoss(Function):
     @staticmethod
     def forward(ctx, cfg, targets, combine, *preds):
         (anchors, grids, na, nc, balance, hbox, hobj, hcls, gr, cp, cn, anchor_t, alpha, flag) = cfg
         nl = len(preds)
-        preds = [p.contiguous() for p in preds]
+        # Detect hands over its (B,na,ny,nx,no) tensors as strided views of the head convolutions' NHWC outputs (no permute copy):
+        # the kernels read and write that layout directly; anything else is made contiguous, the layout of the reference
+        nhwc = all(_is_head_view(p) for p in preds)
+        if not nhwc:
+            preds = [p.contiguous() for p in preds]
         dev = preds[0].device
         bs = preds[0].shape[0]
         idx, tcls, tbox, anch, counts, cap = loss_ops.build_targets_raw(targets, anchors, grids, anchor_t)
@@ -43,7 +55,7 @@ class _DetectLoss(Function):
         ncomb = 0 if combine is None else combine.numel()
         lib.detect_loss(pp, dpp, gh, nl, bs, na, nc, idx.data_ptr(), tcls.data_ptr(), tbox.data_ptr(), anch.data_ptr(),
                         counts.data_ptr(), cap, bh, hbox, hobj, hcls, gr, cp, cn,
-                        combine.data_ptr() if ncomb else None, ncomb, alpha, 1 if flag else 0, ws.data_ptr(), nbytes,
+                        combine.data_ptr() if ncomb else None, ncomb, alpha, (1 if flag else 0) | (2 if nhwc else 0), ws.data_ptr(), nbytes,
                         out5.data_ptr(), _stream())
         ctx.save_for_backward(*dps)
         ctx.mark_non_differentiable(out5)

@@ -313,3 +313,37 @@ def test_twin_model_equals_the_lane_form(kind, width):
             close(ba, bb, 1e-4, 'buffer %s' % k)
         else:
             assert torch.equal(ba, bb), k
+
+
+@pytest.mark.parametrize('switch', ['MMIDET_CAT_DEST', 'MMIDET_HEAD_VIEW'])
+def test_copy_free_concat_and_detect_views_change_nothing(monkeypatch, switch):
+    """Round 3: the neck's Concat layers are aliases of buffers their producers wrote into (models/common.py:740-748 of the
+    reference copies), and Detect hands the loss its (B,na,ny,nx,no) tensors as strided views of the head convolutions' NHWC
+    outputs (models/yolo_test.py:54-55 copies).  Both only remove copies: predictions, loss and every gradient are bit-identical
+    to the copying forms (MMIDET_CAT_DEST=0 / MMIDET_HEAD_VIEW=0)."""
+    from oracle import portable_init
+    from oracle.ref_loss import scaled_hyp
+    from utils.loss import ComputeLoss
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv(switch, '0')
+        m, cfg = _model(True)
+        if switch == 'MMIDET_CAT_DEST':
+            assert bool(m._cat_plan) == (not off)
+        imgs, tg = portable_init.synth_batch(2, 128, cfg['nc'], per_image=4, seed=6)
+        x = imgs.to(dev()).float() / 255
+        m.nc, m.gr, m.hyp = cfg['nc'], 1.0, scaled_hyp(cfg['nc'], 128)
+        pred, comb = m(x[:, :3], x[:, 3:])
+        if switch == 'MMIDET_HEAD_VIEW':
+            assert pred[0].is_contiguous() == off
+        loss, _ = ComputeLoss(m)(pred, tg.to(dev()), comb.reshape(-1))
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        res.append((pred, loss, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
