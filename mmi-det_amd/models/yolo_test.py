@@ -501,6 +501,8 @@ class Model(nn.Module):
             return
         if ops.PACK_C3:
             ops.pack_pair(self)
+        if os.environ.get('MMIDET_PACK_QKV', '1') != '0':
+            F2.pack_qkv(self)          # q/k/v projections of the fusion transformers as one GEMM each way (as TrainStep does)
         w = next(p for p in self.parameters() if p.is_cuda)
         self._pack_key = (w.data_ptr(), w._version)
 

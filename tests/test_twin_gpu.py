@@ -320,7 +320,9 @@ def test_copy_free_concat_and_detect_views_change_nothing(monkeypatch, switch):
     """Round 3: the neck's Concat layers are aliases of buffers their producers wrote into (models/common.py:740-748 of the
     reference copies), and Detect hands the loss its (B,na,ny,nx,no) tensors as strided views of the head convolutions' NHWC
     outputs (models/yolo_test.py:54-55 copies).  Both only remove copies: predictions, loss and every gradient are bit-identical
-    to the copying forms (MMIDET_CAT_DEST=0 / MMIDET_HEAD_VIEW=0)."""
+    to the copying forms (MMIDET_CAT_DEST=0 / MMIDET_HEAD_VIEW=0).  (Bit-identity needs the packed q/k/v projections, which the
+    model sets up at its first forward: the three-GEMM fallback of the transformer blocks' backward is not run-to-run
+    bit-identical -- DESIGN.md section 7.)"""
     from oracle import portable_init
     from oracle.ref_loss import scaled_hyp
     from utils.loss import ComputeLoss
