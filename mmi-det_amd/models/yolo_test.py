@@ -311,8 +311,8 @@ class Model(nn.Module):
         # tensor, on the caller's stream.  Layers outside a pair (and every layer when MMIDET_TWIN=0, in the bf16 storage mode or
         # after fuse()) take the lane form: the IR backbone on its own HIP stream, events at every cross-lane hand-off.
         twin = getattr(self, 'twin', False) and x.is_cuda and not bf16 and x.dtype == torch.float32
-        if twin:
-            self._pack_for_twin()
+        if x.is_cuda:
+            self._pack_for_twin()                                  # (C3 pairs, q/k/v projections: once per placement of the weights)
         lanes = self._lanes if (self.two_streams and x.is_cuda) else None
         main = torch.cuda.current_stream() if lanes else None
         if lanes:

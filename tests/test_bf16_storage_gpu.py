@@ -187,7 +187,7 @@ def test_autocast_selects_the_bf16_storage_mode_when_asked(monkeypatch):
     inv = 1.0 / scaler.get_scale()
     worst = 0.0
     for (n, pa), pb in zip(m_a.named_parameters(), m_b.parameters()):
-        if pb.grad is None:
+        if pb.grad is None or float(pb.grad.abs().max()) < 1e-7:      # (analytically zero: the key bias of a softmax attention)
             continue
         worst = max(worst, rel_err(pa.grad * inv, pb.grad))
     assert worst < 1e-6, worst          # (exact up to the bf16 rounding of activation GRADIENTS, which the scale shifts by 16 binades: none)
