@@ -8,7 +8,6 @@
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TS = 16;  // 16x16 pixel tile per 256-thread workgroup
 

@@ -17,6 +17,14 @@ namespace {
 #ifndef MMI_WGRAD_LDS_B32
 #define MMI_WGRAD_LDS_B32 0
 #endif
+// MMI_WGRAD_PAIR = 1 (fp32 MFMA path): a wave's MFMA sub-tiles INTERLEAVE their rows -- sub-tile i of the TM owns the tile rows
+// TM * r + i, sub-tile j of the TN the columns TN * c + j -- so the TM (TN) fragments a lane feeds to one k-step are TM (TN)
+// CONSECUTIVE floats of the k-major LDS rows: one ds_read_b64 instead of two ds_read_b32 per operand, half the LDS
+// instructions of the K loop (what the in-step A/B above charged for), the same products summed in the same order (results
+// bit-identical); the epilogue writes column pairs as 8-byte stores.  Only which lane holds which output element changes.
+#ifndef MMI_WGRAD_PAIR
+#define MMI_WGRAD_PAIR 1
+#endif
 
 // TAB (pixel-table loaders, the wgrad counterpart of the uniform-tap loaders above).  Here K runs over output pixels, so
 // what every thread of a row has in common is the pixel: per slab ONE wave (taking turns) writes a 32-entry LDS table
@@ -38,6 +46,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   constexpr int NP = PREC == 0 || ONE ? 1 : (PREC == 3 ? 3 : PREC + 1);
   constexpr int OL = ONE ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr bool PAIR = MMI_WGRAD_PAIR && PREC == 0 && !MMI_WGRAD_LDS_B32;   // interleaved sub-tile rows / columns (see above)
   constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
   constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
   // split-bf16 (PREC = 1): both tiles stay k-major in two bf16 planes with rows padded by 64 B; the MFMA operands (8
@@ -387,10 +396,20 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 #else
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if constexpr (PAIR && TM == 2) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(As + (2 * (4 * g + e) + lh) * BM + wm * WM + 2 * l31);
+          a[e][0] = v[0], a[e][TM - 1] = v[1];
+        } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[e][i] = As[(2 * (4 * g + e) + lh) * BM + wm * WM + i * 32 + l31];
+          for (int i = 0; i < TM; ++i) a[e][i] = As[(2 * (4 * g + e) + lh) * BM + wm * WM + i * 32 + l31];
+        }
+        if constexpr (PAIR && TN == 2) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(Bs + (2 * (4 * g + e) + lh) * BN + wn * WN + 2 * l31);
+          b[e][0] = v[0], b[e][TN - 1] = v[1];
+        } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[e][j] = Bs[(2 * (4 * g + e) + lh) * BN + wn * WN + j * 32 + l31];
+          for (int j = 0; j < TN; ++j) b[e][j] = Bs[(2 * (4 * g + e) + lh) * BN + wn * WN + j * 32 + l31];
+        }
       }
 #endif
 #pragma unroll
@@ -426,20 +445,44 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     }
   }
   float* out = p.OUT + (int64_t)split * p.slab_stride;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + l31;
-    if (col < p.Ntot) {
+  // element (i, j, r) of this lane: row (i * 32 + rr) and column (j * 32 + l31) of the wave's sub-tile grid, or -- PAIR -- row
+  // (TM * rr + i) and column (TN * l31 + j), rr = (r & 3) + 8 * (r >> 2) + 4 * lh
+  constexpr bool PM = PAIR && TM == 2, PN = PAIR && TN == 2;
+  const bool pair_store = PN && (p.Ntot & 1) == 0 && ((uintptr_t)out & 7) == 0;  // uniform: column pairs as one 8-byte store
+  if (pair_store) {
+    const int col = n0 + wn * WN + 2 * l31;
+    if (col < p.Ntot) {   // (Ntot even: col + 1 < Ntot as well)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = m0 + wm * WM + (PM ? 2 * rr + i : i * 32 + rr);
           if (row < p.Cout) {
-            if (fold) st_agent(out + (int64_t)row * p.Ntot + col, acc[i][j][r]);
-            else out[(int64_t)row * p.Ntot + col] = acc[i][j][r];
+            const f32x2 v = {acc[i][0][r], acc[i][TN - 1][r]};
+            float* dst = out + (int64_t)row * p.Ntot + col;
+            if (fold) __hip_atomic_store(reinterpret_cast<uint64_t*>(dst), __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *reinterpret_cast<f32x2*>(dst) = v;
           }
         }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WN + (PN ? 2 * l31 + j : j * 32 + l31);
+      if (col < p.Ntot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int row = m0 + wm * WM + (PM ? 2 * rr + i : i * 32 + rr);
+            if (row < p.Cout) {
+              if (fold) st_agent(out + (int64_t)row * p.Ntot + col, acc[i][j][r]);
+              else out[(int64_t)row * p.Ntot + col] = acc[i][j][r];
+            }
+          }
+      }
     }
   }
   if (!fold) return;
