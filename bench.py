@@ -367,6 +367,23 @@ def main():
             # (no device_id=: binding the group to the device at init makes every later step ~5 ms slower on this
             # torch/RCCL; torch.cuda.set_device above already pins the rank to its GPU)
             dist.init_process_group('nccl', rank=rank, world_size=world)
+    # tools/ab_comm3.sh (world 1, no reducer, the plain single-GPU step): which part of a transport's SET-UP changes the step time
+    # -- 'gloo' = a gloo process group exists, 'rccl' = the library's communicator exists, 'nccl' = a ProcessGroupNCCL that has
+    # run one collective exists; combinations with '+'
+    bisect = os.environ.get('MMIDET_COMM_BISECT', '') if not ddp else ''
+    if bisect:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        parts = bisect.split('+')
+        if 'gloo' in parts:
+            dist.init_process_group('gloo', rank=0, world_size=1)
+        elif 'nccl' in parts:
+            dist.init_process_group('nccl', rank=0, world_size=1)
+            dist.barrier()
+        if 'rccl' in parts:
+            from mmidet_hip.ddp import init_native_comm
+            init_native_comm(0, 1)
     ctl_dev = dev if (ddp and comm_kind != 'native') else torch.device('cpu')   # where control-plane tensors live
 
     from mmidet_hip.train_step import TrainStep
@@ -625,6 +642,13 @@ def main():
             torch.cuda.synchronize()
             _l.comm_destroy()
         dist.destroy_process_group()
+    if bisect:
+        from mmidet_hip import lib as _l
+        torch.cuda.synchronize()
+        if _l.comm_world() > 0:
+            _l.comm_destroy()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -394,11 +394,23 @@ class _TransformerBlock(Function):
                                   dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, ldq, d, ps[0], seeds[0],
                                   sd if ps[0] > 0 else None, s)
         dln1 = torch.empty_like(x)
-        for i, (dy, w, b) in enumerate(((dq, wq, bq), (dk_, wk, bk), (dv, wv, bv))):
-            wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d, ldq)
-            if not packed:
+        if packed and all(need[2:8]) and not ops.GRAD_SLOTS:
+            # the three projections' weight (and bias) gradients as ONE GEMM into one (3d, d) buffer: the parameters lie back
+            # to back, their gradients may as well (each .grad is a row block of it); 3d x d output tiles instead of three
+            # launches of d x d ones (the K dimension is 2048 tokens: short, so tiles are what fills the chip)
+            dwp = torch.empty((3 * d, d), dtype=wq.dtype, device=dev)
+            dbp = torch.empty(3 * d, dtype=bq.dtype, device=dev)
+            dd = ConvDesc(rows, 1, 1, d, 1, 1, 3 * d, 1, 1, 1, 0, d, 3 * d)
+            ops._wgrad(dqkv, 3 * d, ln1y, d, wq, dd, overlap=ops.OVERLAP_WGRAD, want_bias=True, out=(dwp, dbp))
+            for i in range(3):
+                grads[2 + 2 * i], grads[3 + 2 * i] = dwp[i * d:(i + 1) * d], dbp[i * d:(i + 1) * d]
+        else:
+            for i, (dy, w, b) in enumerate(((dq, wq, bq), (dk_, wk, bk), (dv, wv, bv))):
+                wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d, ldq)
+        if not packed:
+            for i, (dy, w) in enumerate(((dq, wq), (dk_, wk), (dv, wv))):
                 _linear_dgrad(dy, w, dln1, rows, d, d, s, EPI_ACCUMULATE if i else EPI_NONE, aux=dln1 if i else None)
-        if packed:
+        else:
             _linear_dgrad(dqkv, wq, dln1, rows, d, 3 * d, s)
         if need[0] or need[1]:
             grads[0], grads[1] = _ln_param_grads(x, st1, dln1, g1, b1, rows, d)

@@ -230,13 +230,18 @@ def wgrad_table(d, device):
     return ent[0]
 
 
-def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None):
+def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None, out=None):
     """dw = dy^T x.  With overlap=True the kernel is enqueued on the side stream behind everything already on the
     current stream; the caller must `_join_side()` before the current stream (or anyone else) touches dw.  dgrad and wgrad
     of one layer are independent, and two co-running grids fill each other's partial last wave (the fp32-MFMA kernels
-    lose up to a third of the chip to wave quantisation when they run alone)."""
-    dw = grad_like(w)
-    db = (grad_like(bias) if bias is not None else torch.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
+    lose up to a third of the chip to wave quantisation when they run alone).
+    out = (dw, db or None): caller-owned outputs (several parameters that lie back to back and take one GEMM: pack_qkv)."""
+    if out is not None:
+        dw, db = out
+        assert (db is not None) == bool(want_bias)
+    else:
+        dw = grad_like(w)
+        db = (grad_like(bias) if bias is not None else torch.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
     dbp = db.data_ptr() if want_bias else None
     k = _desc_key(d)
     nbytes = _wgrad_ws.get(k)
@@ -548,8 +553,15 @@ class _DualConvBnAct(Function):
         _bn_act_bwd(y, cout, da, lda, db, ldb, c_, mi, g1, b1, dy, (dg1, dbt1, dg2, dbt2), rows, cout, act, 0 if training else 1, s)
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0]
         d1 = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, c_, 1, 1, 1, 0, d.ldx, cout)
-        dw1 = _wgrad(dy[..., :c_], cout, x, d.ldx, w1, d1, overlap=both) if ctx.needs_input_grad[1] else None
-        dw2 = _wgrad(dy[..., c_:], cout, x, d.ldx, w2, d1, overlap=both) if ctx.needs_input_grad[2] else None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and not GRAD_SLOTS and dy.dtype == torch.float32:
+            # one (2c_, Cin) gradient matrix for the packed pair, each parameter's .grad a row block of it: one launch
+            flat = torch.empty(cout * d.Cin, dtype=w1.dtype, device=x.device)
+            dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.ldx, cout)
+            _wgrad(dy, cout, x, d.ldx, w1, dd, overlap=both, out=(flat, None))
+            dw1, dw2 = (flat[i * c_ * d.Cin:(i + 1) * c_ * d.Cin].as_strided(w1.shape, w1.stride()) for i in range(2))
+        else:
+            dw1 = _wgrad(dy[..., :c_], cout, x, d.ldx, w1, d1, overlap=both) if ctx.needs_input_grad[1] else None
+            dw2 = _wgrad(dy[..., c_:], cout, x, d.ldx, w2, d1, overlap=both) if ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)

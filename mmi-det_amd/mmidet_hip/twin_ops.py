@@ -130,12 +130,12 @@ def dgrad2(dy, cout, wa, wb, dx, d, skip=None, s=None):
                         cin, s)
 
 
-def wgrad2(dy, dy_off, lddy, lsdy, x, ldx, lsx, wa, wb, cout, k, stride, shape, overlap):
+def wgrad2(dy, dy_off, lddy, lsdy, x, ldx, lsx, wa, wb, cout, k, stride, shape, overlap, out=None):
     """(dwa, dwb) = dy_g^T x_g for both lanes in one launch, on the wgrad side stream when overlap (ops._wgrad's conventions:
-    deferred join keeps the operands alive)."""
+    deferred join keeps the operands alive).  out = (dwa, dwb): caller-owned outputs of cout rows each (packed parameters)."""
     n, h, w, cin = shape
     d = ops._desc((n, h, w, cin), cout, k, stride, ldx, lddy)
-    dwa, dwb = grad_like(wa), grad_like(wb)
+    dwa, dwb = out if out is not None else (grad_like(wa), grad_like(wb))
     key = ('w',) + ops._desc_key(d)
     nb = _plan.get(key)
     if nb is None:
@@ -295,9 +295,17 @@ class _TwinDualConvBnAct(Function):
                            dy.data_ptr(), 4 * c_, rows, 4 * c_, act, 0 if training else 1, s)
         need_x = ctx.needs_input_grad[0]
         both = ops.OVERLAP_WGRAD and need_x
-        # the four weight gradients: cv1 of both lanes, cv2 of both lanes (each parameter keeps its own .grad)
-        dw1a, dw1b = wgrad2(dy, 0, 4 * c_, 2 * c_, x, ldx, lsx, w1a, w1b, c_, 1, 1, (n, h, w, cin), both)
-        dw2a, dw2b = wgrad2(dy, c_, 4 * c_, 2 * c_, x, ldx, lsx, w2a, w2b, c_, 1, 1, (n, h, w, cin), both)
+        if ops.GRAD_SLOTS or not all(ctx.needs_input_grad[1:5]):
+            # the four weight gradients: cv1 of both lanes, cv2 of both lanes (each lands in its parameter's bucket view)
+            dw1a, dw1b = wgrad2(dy, 0, 4 * c_, 2 * c_, x, ldx, lsx, w1a, w1b, c_, 1, 1, (n, h, w, cin), both)
+            dw2a, dw2b = wgrad2(dy, c_, 4 * c_, 2 * c_, x, ldx, lsx, w2a, w2b, c_, 1, 1, (n, h, w, cin), both)
+        else:
+            # cv1 | cv2 are one (2c_, Cin) matrix per lane (ops.pack_pair), and so is their gradient: ONE twin launch with 2c_
+            # output rows; each parameter's .grad is a row block of the lane's buffer
+            fa, fb = (torch.empty(2 * c_ * cin, dtype=w1a.dtype, device=x.device) for _ in range(2))
+            wgrad2(dy, 0, 4 * c_, 2 * c_, x, ldx, lsx, w1a, w1b, 2 * c_, 1, 1, (n, h, w, cin), both, out=(fa, fb))
+            dw1a, dw2a = (fa[i * c_ * cin:(i + 1) * c_ * cin].as_strided(w1a.shape, w1a.stride()) for i in range(2))
+            dw1b, dw2b = (fb[i * c_ * cin:(i + 1) * c_ * cin].as_strided(w1b.shape, w1b.stride()) for i in range(2))
         dx = None
         if need_x:
             dx = torch.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)

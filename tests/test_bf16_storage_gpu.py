@@ -241,3 +241,39 @@ def test_bf16_storage_training_overfits_one_batch():
             losses.append(float(items[3]))
     assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point)
     assert losses[-1] < 0.85 * losses[0], losses
+
+
+def test_bf16_storage_loss_curve_tracks_fp32_over_300_steps():
+    """Qualification without a dataset: the same model, initialisation and cyclic stream of 12 synthetic batches
+    trained for 300 steps in the fp32 parity mode and in the bf16 storage mode.  Criterion: everything finite, both curves fall,
+    and after smoothing over one pass of the stream the two curves stay within 10 % of each other (measured at this size: see
+    DESIGN.md, bf16 storage mode; at yolov5l 640^2 B=16 the same experiment gives 4.0 % max / 1.3 % mean,
+    profiles/r03_bf16_storage_loss_tracking_l_fourier_300steps.json, tools/track_storage_modes.py)."""
+    from mmidet_hip import fusion_ops, lib
+    from test_step_gpu import batch, make
+    curves = {}
+    nb, steps = 12, 300
+    try:
+        for storage in ('f32', 'bf16'):
+            torch.manual_seed(2)
+            fusion_ops._seed_state.pop(dev(), None)
+            fusion_ops._drop_counter[0] = 0
+            m, ts, cfg = make('fourier', dropout=0.1)
+            m.storage = storage
+            lib.set_gemm_precision(5 if storage == 'bf16' else 0)
+            stream = [batch(cfg, 700 + i) for i in range(nb)]
+            ls = []
+            for it in range(steps):
+                loss, _ = ts.step(*stream[it % nb])
+                ls.append(loss.detach())
+            torch.cuda.synchronize()
+            curves[storage] = [float(v) for v in ls]
+            assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point), storage
+    finally:
+        lib.set_gemm_precision(0)
+    sm = {k: [sum(v[i:i + nb]) / nb for i in range(0, steps - nb + 1)] for k, v in curves.items()}
+    gap = max(abs(a - b) / abs(a) for a, b in zip(sm['f32'], sm['bf16']))
+    print('smoothed curves: f32 %.4f -> %.4f, bf16 %.4f -> %.4f, max relative gap %.4f' % (sm['f32'][0], sm['f32'][-1], sm['bf16'][0],
+                                                                                          sm['bf16'][-1], gap))
+    assert sm['f32'][-1] < sm['f32'][0] and sm['bf16'][-1] < sm['bf16'][0], 'both runs must learn the stream'
+    assert gap < 0.10, gap
