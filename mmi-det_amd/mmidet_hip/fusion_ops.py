@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 
 from . import lib, ops
-from .lib import (EPI_ACCUMULATE, EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_NONE, ConvDesc, LinearEpilogue)
+from .lib import (EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_NONE, ConvDesc, LinearEpilogue)
 from .ops import _nrows, _stream, grad_like, rows_of, scratch, zeroed_scratch
 
 _drop_counter = [0]
@@ -257,8 +257,8 @@ def _back_to_back(a, b, c):
 def pack_qkv(model):
     """Re-seat que_proj / key_proj / val_proj of every SelfAttention (models/common.py:1167-1169 of the reference) on one
     (3d, d) weight and one (3d,) bias buffer: same Parameters, same state_dict keys, same values, but the three projections
-    now run as ONE GEMM forward and ONE input-gradient GEMM (_TransformerBlock checks the addresses on every call, so a
-    model whose parameters were moved afterwards, e.g. by .to(), silently takes the three-GEMM path again).
+    then need no gathering copy per call (_TransformerBlock checks the addresses on every call; a model whose parameters were
+    moved afterwards, e.g. by .to(), runs the same kernels on a gathered copy of the three matrices).
     Call before anything caches parameter addresses (optimizer pointer tables, gradient buckets).  Returns the count."""
     n = 0
     for m in model.modules():
@@ -302,8 +302,8 @@ def _ln_param_grads(x, stats, dy, gamma, beta, rows, c):
 class _TransformerBlock(Function):
     """myTransformerBlock (models/common.py:1237-1267 of the reference) as one autograd node:
         x1 = x + drop(out_proj(attention(q, k, v)(ln_input(x))));  x2 = x1 + drop(mlp2(GELU(mlp0(ln_output(x1)))))
-    Forward 9 dependent kernels (LayerNorm, q/k/v, attention, out_proj+dropout+residual, LayerNorm, mlp0+GELU,
-    mlp2+dropout+residual), backward 11 on the chain; weight, bias and LayerNorm-parameter gradients run on the side stream.
+    Forward 7 dependent kernels (LayerNorm, the q|k|v projection, attention, out_proj+dropout+residual, LayerNorm, mlp0+GELU,
+    mlp2+dropout+residual), backward 9 on the chain; weight, bias and LayerNorm-parameter gradients run on the side stream.
     The token chains are launch-latency bound (2048 rows x 128..1024 channels), so the kernel count is their cost."""
 
     @staticmethod
@@ -317,18 +317,17 @@ class _TransformerBlock(Function):
         new = lambda *shape: torch.empty(shape, dtype=x.dtype, device=dev)  # noqa: E731
         ln1y, st1 = torch.empty_like(x), new(rows, 2)
         lib.layernorm_fwd(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), ln1y.data_ptr(), st1.data_ptr(), rows, d, eps[0], s)
-        packed = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)      # pack_qkv(): one projection GEMM
-        if packed:
-            qkv = new(bsz, t, 3 * d)
-            _linear_fwd(ln1y, wq, bq, qkv, rows, d, 3 * d, s)
-            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        else:
-            q, k, v = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-            for w, b, out in ((wq, bq, q), (wk, bk, k), (wv, bv, v)):
-                _linear_fwd(ln1y, w, b, out, rows, d, d, s)
+        # q, k, v are ONE projection GEMM over the (3d, d) weight pack_qkv() lays out.  Parameters that do not lie back to back
+        # (a model whose parameters were moved after packing, or that never was packed) are gathered into such a matrix here:
+        # the same kernels, the same numbers, one small copy per block instead of a second code path.
+        packed = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
+        wqkv, bqkv = (wq, bq) if packed else (torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0))
+        qkv = new(bsz, t, 3 * d)
+        _linear_fwd(ln1y, wqkv, bqkv, qkv, rows, d, 3 * d, s)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         o, probs = torch.empty_like(x), new(bsz, heads, t, t)
         lib.attention_fwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), probs.data_ptr(), bsz, heads,
-                                  d // heads, 3 * d if packed else d, d, ps[0], seeds[0], sd if ps[0] > 0 else None, s)
+                                  d // heads, 3 * d, d, ps[0], seeds[0], sd if ps[0] > 0 else None, s)
         x1 = torch.empty_like(x)
         _linear_fwd(o, wo, bo, x1, rows, d, d, s, EPI_DROPOUT_RESIDUAL, aux=x, p=ps[1], seed=seeds[1],
                     seed_dev=sd if ps[1] > 0 else None)
@@ -384,17 +383,15 @@ class _TransformerBlock(Function):
         wgrad(dy1, o, wo, bo, 8, d, d)
         do = torch.empty_like(x)
         _linear_dgrad(dy1, wo, do, rows, d, d, s)
-        ldq = 3 * d if packed else d
-        if packed:
-            dqkv = torch.empty((bsz, t, 3 * d), dtype=x.dtype, device=dev)
-            dq, dk_, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
-        else:
-            dq, dk_, dv = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        ldq = 3 * d
+        dqkv = torch.empty((bsz, t, 3 * d), dtype=x.dtype, device=dev)
+        dq, dk_, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
         lib.attention_bwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
                                   dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, ldq, d, ps[0], seeds[0],
                                   sd if ps[0] > 0 else None, s)
         dln1 = torch.empty_like(x)
-        if packed and all(need[2:8]) and not ops.GRAD_SLOTS:
+        wqkv = wq if packed else torch.cat([wq, wk, wv], 0)      # (see forward)
+        if all(need[2:8]) and not ops.GRAD_SLOTS:
             # the three projections' weight (and bias) gradients as ONE GEMM into one (3d, d) buffer: the parameters lie back
             # to back, their gradients may as well (each .grad is a row block of it); 3d x d output tiles instead of three
             # launches of d x d ones (the K dimension is 2048 tokens: short, so tiles are what fills the chip)
@@ -407,11 +404,7 @@ class _TransformerBlock(Function):
         else:
             for i, (dy, w, b) in enumerate(((dq, wq, bq), (dk_, wk, bk), (dv, wv, bv))):
                 wgrad(dy, ln1y, w, b, 2 + 2 * i, d, d, ldq)
-        if not packed:
-            for i, (dy, w) in enumerate(((dq, wq), (dk_, wk), (dv, wv))):
-                _linear_dgrad(dy, w, dln1, rows, d, d, s, EPI_ACCUMULATE if i else EPI_NONE, aux=dln1 if i else None)
-        else:
-            _linear_dgrad(dqkv, wq, dln1, rows, d, 3 * d, s)
+        _linear_dgrad(dqkv, wqkv, dln1, rows, d, 3 * d, s)
         if need[0] or need[1]:
             grads[0], grads[1] = _ln_param_grads(x, st1, dln1, g1, b1, rows, d)
         dx = torch.empty_like(x)

@@ -262,6 +262,43 @@ def test_transformer_block_matches_oracle(B, C, packed):
         close(pg.grad, pr.grad, tol=2e-3, what=n)
 
 
+def test_transformer_block_unpacked_parameters_take_the_packed_kernels_bit_for_bit():
+    """Parameters that do not lie back to back (never packed, or moved after packing) are gathered into a (3d, d) matrix per call
+    and run the SAME kernels as the packed layout: outputs and all gradients equal bit for bit, and run to run (round 3: the
+    separate three-projection path this replaces was not run-to-run bit-identical)."""
+    import models.common as mc
+    from mmidet_hip import fusion_ops as F2
+    d = dev()
+    torch.manual_seed(11)
+    B, C = 16, 256
+    blk = mc.myTransformerBlock(C, C, C, 8, 4, 0.1, 0.1).to(d).train()
+    for p in blk.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(B, 128, C, device=d)
+    go = torch.randn(B, 128, C, device=d)
+    ps, seeds, eps = (0.1, 0.1, 0.1), (5, 6, 7), (1e-5, 1e-5)
+
+    def run():
+        prm = _block_params(blk)
+        for p in prm:
+            p.grad = None
+        xg = x.clone().requires_grad_()
+        y = F2._TransformerBlock.apply(xg, 8, ps, eps, seeds, *prm)
+        y.backward(go)
+        torch.cuda.synchronize()
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in prm]
+
+    assert not F2._back_to_back(blk.sa.que_proj.weight, blk.sa.key_proj.weight, blk.sa.val_proj.weight)
+    a, b = run(), run()
+    for p in blk.parameters():
+        p.grad = None            # (pack_qkv leaves parameters alone whose .grad is set)
+    assert F2.pack_qkv(blk) == 1
+    c = run()
+    for i, (u, v, w) in enumerate(zip(a, b, c)):
+        assert torch.equal(u, v), 'tensor %d differs between two runs of the unpacked layout' % i
+        assert torch.equal(u, w), 'tensor %d differs between the unpacked and the packed layout' % i
+
+
 def test_transformer_block_dropout_matches_unfused_kernels():
     """With dropout the fused node must draw the masks the separate kernels draw from the same salts (same hash, same
     element index) and use them again in the backward: compare with the block composed of the single-op kernels."""
