@@ -624,7 +624,14 @@ def main():
                 'note': 'NOT the headline (which uses exact fp32 MFMA products): the same step with mmi_set_gemm_precision(3 / 2 / 1); '
                         'off by default, see DESIGN.md',
                 **{k: {'value': round(world * bs / v[0], 3), 'unit': 'paired img/s', 'ms_per_step': round(v[0] * 1e3, 3),
-                       'loss_finite': v[1], 'last_loss': v[2], 'arithmetic': what[k]} for k, v in split.items()}}
+                       'loss_finite': v[1], 'last_loss': v[2], 'arithmetic': what[k],
+                       # step-level roofline of the mode: the step's algorithmic FLOPs against the bf16 MFMA peak (16x the fp32
+                       # MFMA rate, MI355X_MICROARCH.md) divided by the bf16 products one fp32 product costs in this mode
+                       'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s (fp32-equivalent, whole step)',
+                                    'achieved': round(3 * WORKLOADS[args.workload][6] * 1e9 * world * bs / v[0] / 1e12, 2),
+                                    'peak': round(16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:]), 1),
+                                    'frac': round(3 * WORKLOADS[args.workload][6] * 1e9 * world * bs / v[0] / 1e12
+                                                  / (16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:])), 4)}} for k, v in split.items()}}
         if pcie is not None:
             out['pcie_inclusive'] = pcie
         if not args.no_roofline and args.workload != 's_add':

@@ -15,7 +15,10 @@ int sk_occupancy(int bn) {
 #define OCC(P_) (bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, P_>, 256, 0) \
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, P_>, 256, 0))
     // (fp32: the uniform-tap variant is what nearly every stream-K shape runs; the few others fit its grid as well)
-    if (g_gemm_prec == 0 && g_uniform_loaders)
+    if (g_gemm_prec == 2 && g_uniform_loaders)
+      e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 2, false, true>, 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 2, false, true>, 256, 0);
+    else if (g_gemm_prec == 0 && g_uniform_loaders)
       e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 0, false, true>, 256, 0)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 0, false, true>, 256, 0);
     else
@@ -42,7 +45,9 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   if (p.mi_stride == 0) p.mi_stride = p.Ncol;
   // uniform-tap loaders (igemm_kernel<..., UNI>): whole slabs inside one tap, tap table in 32 bits, 31-bit byte offsets
   bool uni = false;
-  if (vec && g_uniform_loaders && g_gemm_prec == 0 && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
+  // (fp32 MFMA and -- round 3 -- the six-product split, the mode reported beside the headline; the other split forms keep the
+  //  cursor loaders: every (PREC, UNI) pair is another set of kernel variants to build)
+  if (vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2) && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
     const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;
     const int64_t npix = (int64_t)(p.M / ((int64_t)p.P * p.Q)) * p.Hs * p.Ws;
     const int64_t a_bytes = (margin + (npix - 1) * p.lda + p.Kc) * 4;
@@ -99,7 +104,10 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       return MMI_OK;
     }
     if (g_gemm_prec == 2) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p, q);
+      if (uni) {
+        if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI, true>), grid, block, 0, s, p, q);
+        else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI, true>), grid, block, 0, s, p, q);
+      } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p, q);
       else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 2, EPI>), grid, block, 0, s, p, q);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
@@ -121,6 +129,15 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1, nz), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p, q)
+  if (vec && g_gemm_prec == 2 && uni) {
+#define LAUNCH_U2(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI, true>), grid, block, 0, s, p, q)
+    if (f.bm == 128 && f.bn == 128) LAUNCH_U2(128, 128);
+    else if (f.bm == 128 && f.bn == 64) LAUNCH_U2(128, 64);
+    else LAUNCH_U2(64, 64);
+#undef LAUNCH_U2
+    MMI_CHECK_LAUNCH(who);
+    return MMI_OK;
+  }
   if (vec && g_gemm_prec >= 1) {
 #define LAUNCH_B3(BM_, BN_)                                                                                          \
   do {                                                                                                               \

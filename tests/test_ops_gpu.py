@@ -275,11 +275,14 @@ def test_build_targets_bit_exact(tag, bs, per):
 
 @pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (2, 21, 23, 32, 64, 3, 2), (2, 16, 16, 128, 256, 1, 1), (4, 40, 40, 128, 128, 3, 1),
                                   (1, 33, 17, 96, 64, 3, 1)])
-def test_uniform_loaders_are_bit_identical_to_the_general_ones(case):
+@pytest.mark.parametrize('mode', [0, 2], ids=['fp32', 'bf16x6'])
+def test_uniform_loaders_are_bit_identical_to_the_general_ones(case, mode):
     """mmi_set_uniform_loaders: the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders only change how a tile's
     addresses are formed; the arithmetic and its order are those of the general cursor-based loaders, so y, dx and dw must be
-    equal bit for bit -- including zero padding at the borders, ragged tiles and the stride-2 parity classes."""
+    equal bit for bit -- including zero padding at the borders, ragged tiles and the stride-2 parity classes.  Both arithmetics
+    that have these loaders: the fp32 MFMA default and the six-product split (mmi_set_gemm_precision(2))."""
     from mmidet_hip import lib, ops
+    lib.set_gemm_precision(mode)
     N, H, W, Ci, Co, k, s = case
     d = dev()
     g = torch.Generator().manual_seed(sum(case))
@@ -303,5 +306,6 @@ def test_uniform_loaders_are_bit_identical_to_the_general_ones(case):
             outs.append((y, dx, dw, part[:lib.conv_fwd_row_blocks(desc) * 2 * Co].clone()))
     finally:
         lib.set_uniform_loaders(1)
+        lib.set_gemm_precision(0)
     for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dw', 'BN statistics partials')):
         assert torch.equal(a, b), what
