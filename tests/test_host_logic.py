@@ -175,3 +175,60 @@ def test_fan_out_plan_of_the_default_graph():
     m3 = Model.__new__(Model)
     m3.__setstate__(old)
     assert m3._fan_skip == plan
+
+
+def test_twin_and_concat_plans_of_the_shipped_graphs():
+    """yolo_test._plan_twins / _plan_concats (host logic of round 3's launch structure).  Twin plan: every IR-backbone layer is paired
+    with the RGB-backbone layer of the same type and parameter shapes whose inputs are themselves a pair (or the two images), pairs
+    are one-to-one, and a leader precedes its follower.  Concat plan: a planned Concat's producers are distinct single-use layers
+    that can write a channel slice, their offsets tile the buffer exactly, and no planned producer is a twin layer."""
+    import sys
+    sys.path[:0] = [REPO, os.path.join(REPO, 'mmi-det_amd')]
+    import bench
+    from models.common import Add, Add2, Concat, Conv, Focus
+    from models.yolo_test import Model, Upsample2x
+    for name, npairs in (('l_fourier', 14), ('s_add', None)):
+        m = Model(bench.load_cfg(name))
+        lead, fol = m._leader_of, m._follower_of
+        assert len(lead) == len(fol) > 0 and (npairs is None or len(lead) == npairs), (name, len(lead))
+        assert {v: k for k, v in fol.items()} == lead                              # one-to-one
+        for j, i in lead.items():
+            mi, mj = m.model[i], m.model[j]
+            assert i < j and type(mi) is type(mj) and not m._lanes[i] and m._lanes[j]
+            assert [tuple(p.shape) for p in mi.parameters()] == [tuple(p.shape) for p in mj.parameters()]
+            if isinstance(mj, Focus):
+                continue
+            si, sj = m._srcs[i], m._srcs[j]
+            if isinstance(mj, Add2):
+                assert lead.get(sj[0]) == si[0] and si[1] == sj[1]
+            else:
+                assert len(si) == len(sj) == 1 and lead.get(sj[0]) == si[0]
+        if name == 's_add':
+            assert all(j - i == 10 for j, i in lead.items())                     # fusion_add graphs: row i <-> row i + 10
+        # concat plan
+        assert m._cat_total, name
+        for cat, total in m._cat_total.items():
+            assert isinstance(m.model[cat], Concat)
+            prods = [(off, j) for j, (c, off) in m._cat_plan.items() if c == cat]
+            assert sorted(j for _, j in prods) == sorted(m._srcs[cat])
+            width = 0
+            for off, j in sorted(prods):
+                assert off == width and isinstance(m.model[j], (Conv, Add, Upsample2x)) and j not in lead and j not in fol
+                width += _width_of(m, j)
+            assert width == total
+        m.fuse()
+        assert not m._cat_plan and not m.twin                                        # inference graph: plain layers
+
+
+def _width_of(m, j):
+    """channels of a pass-through layer's output (Add / Upsample2x): those of the Conv / C3 / SPP that feeds it."""
+    from models.common import C3, SPP, Conv
+    while True:
+        layer = m.model[j]
+        if isinstance(layer, Conv):
+            return layer.conv.weight.shape[0]
+        if isinstance(layer, C3):
+            return layer.cv3.conv.weight.shape[0]
+        if isinstance(layer, SPP):
+            return layer.cv2.conv.weight.shape[0]
+        j = m._srcs[j][0]
