@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   // fp32 master copies, rounded when a tile is staged), one bf16 MFMA product per element pair, fp32 accumulation, fp32
   // BatchNorm statistics taken from the accumulators.  Same tile machinery as the split forms with a single plane.
   constexpr bool BF = PREC == 4;
-  static_assert(!BF || !UNI, "bf16 storage uses the cursor loaders");
+  constexpr int ES = BF ? 2 : 4;   // bytes per element of the activation operand A (UNI: byte offsets against a buffer resource)
   // PREC = 5 ("bf16x1"): fp32 operands in HBM, each rounded to ONE bf16 term when staged, one bf16 MFMA product: the arithmetic of
   // the bf16-storage mode for the GEMMs whose operands stay fp32 (the token-side Linear layers, Focus, Detect)
   constexpr bool ONE = BF || PREC == 5;
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   const int l31 = lane & 31, lh = lane >> 5;
   __amdgpu_buffer_rsrc_t srd_a, srd_b;
   if constexpr (UNI) {
-    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;  // floats in front of A that row offsets may reach into
-    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - margin), 0, (int)p.a_bytes, 0x00020000);
+    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;  // elements in front of A that row offsets may reach into
+    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) - margin * ES), 0, (int)p.a_bytes, 0x00020000);
     srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   }
 
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         amask[i] = 0xFFFFFFFFu;
         if (lin1) {
           if (rows[i].base >= 0) {
-            aoff[i] = (uint32_t)((((int64_t)(m0 + lrow + RPP * i) + p.Ws + 1) * p.lda + kq) * 4);  // margin = KH*Ws + KW pixels
+            aoff[i] = (uint32_t)((((int64_t)(m0 + lrow + RPP * i) + p.Ws + 1) * p.lda + kq) * ES);  // margin = KH*Ws + KW pixels
             amask[i] = 0u;
           }
         } else if (rows[i].base >= 0) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           const int iwb = DGRAD ? ((rows[i].qw - tp.kw0) >> u_sh) : rows[i].qw + tp.kw0;
           const int ihlo = DGRAD ? ihb - u_dh * (u_nth - 1) : ihb, iwlo = DGRAD ? iwb - u_dw * (tp.ntw - 1) : iwb;
           const int64_t pix = rows[i].base + (int64_t)(ihlo + p.KH) * p.Ws + iwlo + p.KW;
-          aoff[i] = (uint32_t)((pix * p.lda + kq) * 4);
+          aoff[i] = (uint32_t)((pix * p.lda + kq) * ES);
           // separable: a tap is out if its row is out or its column is out
           uint32_t bw = 0, bad = 0;
           for (int tj = 0; tj < tp.ntw; ++tj)
@@ -411,9 +411,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
       if constexpr (UNI) {
         const int tap = u_ti * tp.ntw + u_tj;
         const int dpix = DGRAD ? (u_nth - 1 - u_ti) * u_dh * p.Ws + (tp.ntw - 1 - u_tj) * u_dw : u_ti * u_dh * p.Ws + u_tj * u_dw;
-        const uint32_t soff = (uint32_t)(dpix * p.lda + u_c0) * 4u;
+        const uint32_t soff = (uint32_t)(dpix * p.lda + u_c0) * (uint32_t)ES;
         const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe(amask[i], tap, 1);   // -1 where this tap leaves the image
-        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
+        if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, aoff[i] | (inv & OOB), soff, 0));
+        else ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
         return;
       }
       int64_t pix = 0;
@@ -696,7 +697,8 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
       float s1 = 0.f, s2 = 0.f;
       if (UNI && fast_store) {
         const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
-        const uint32_t voff = (uint32_t)(((m0 + wm * WM + 4 * lh) * p.ldc + col) * 4);
+        constexpr int CS = BF ? 2 : 4;   // bytes per output element
+        const uint32_t voff = (uint32_t)(((m0 + wm * WM + 4 * lh) * p.ldc + col) * CS);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -704,8 +706,9 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
             const float v = acc[i][j][r] + bv;
             s1 += v;
             s2 = __builtin_fmaf(v, v, s2);  // (explicit, so that both epilogue forms round alike)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_c, voff,
-                                                  (uint32_t)((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc) * 4u, 0);
+            const uint32_t so = (uint32_t)((i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc) * (uint32_t)CS;
+            if constexpr (BF) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), srd_c, voff, so, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), srd_c, voff, so, 0);
           }
         }
       } else

@@ -197,6 +197,24 @@ int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who
   if (p.mi_stride == 0) p.mi_stride = p.Ncol;
   const IgemmDelta q{};   // (single problem)
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1), block(256);
+  // uniform-tap loaders (round 3: also for the 2-byte activation operand; same conditions as launch_igemm)
+  if (g_uniform_loaders && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
+    const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;
+    const int64_t npix = (int64_t)(p.M / ((int64_t)p.P * p.Q)) * p.Hs * p.Ws;
+    const int64_t a_bytes = (margin + (npix - 1) * p.lda + p.Kc) * 2;
+    const int64_t b_bytes = DGRAD ? (int64_t)p.Kc * p.ldb * 4 : (int64_t)p.Ncol * p.ldb * 4;
+    if (a_bytes < (1LL << 31) && b_bytes < (1LL << 31)) {
+      p.a_bytes = (uint32_t)a_bytes;
+      p.b_bytes = (uint32_t)b_bytes;
+      const int64_t c_bytes = ((int64_t)(p.M - 1) * p.ldc + p.Ncol) * 2;
+      p.c_bytes = c_bytes < (1LL << 31) ? (uint32_t)c_bytes : 0u;
+      if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI, true>), grid, block, 0, s, p, q);
+      else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI, true>), grid, block, 0, s, p, q);
+      else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI, true>), grid, block, 0, s, p, q);
+      MMI_CHECK_LAUNCH(who);
+      return MMI_OK;
+    }
+  }
   if (f.bm == 128 && f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
   else if (f.bm == 128 && f.bn == 64) hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);
   else hipLaunchKernelGGL((igemm_kernel<64, 64, DGRAD, true, false, 4, EPI>), grid, block, 0, s, p, q);

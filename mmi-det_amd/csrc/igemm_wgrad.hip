@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
-  static_assert(!BF || !TAB, "bf16 storage uses the cursor loaders");
+  constexpr int ES = BF ? 2 : 4;   // bytes per element of dy and x (TAB: byte offsets against buffer resources)
   constexpr bool ONE = BF || PREC == 5;   // PREC = 5: fp32 operands, one bf16 term each (see igemm_kernel)
   constexpr int NP = PREC == 0 || ONE ? 1 : (PREC == 3 ? 3 : PREC + 1);
   constexpr int OL = ONE ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   __amdgpu_buffer_rsrc_t srd_x;
   if constexpr (TAB) {
 #pragma unroll
-    for (int i = 0; i < ITA; ++i) a_voff[i] = am < p.Cout ? (uint32_t)(((akr + RPA * i) * p.ldy + am) * 4) : OOB;
+    for (int i = 0; i < ITA; ++i) a_voff[i] = am < p.Cout ? (uint32_t)(((akr + RPA * i) * p.ldy + am) * ES) : OOB;
     b_tapbit = b_kh[0] * p.KW + b_kw[0];
-    b_tapoff = b_ok[0] ? (uint32_t)(((b_kh[0] * p.W + b_kw[0]) * p.ldx + b_ci[0]) * 4) : OOB;
+    b_tapoff = b_ok[0] ? (uint32_t)(((b_kh[0] * p.W + b_kw[0]) * p.ldx + b_ci[0]) * ES) : OOB;
     const int64_t margin = ((int64_t)p.KH * p.W + p.KW) * p.ldx;
-    srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X - margin), 0, (int)p.x_bytes, 0x00020000);
+    srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.X) - margin * ES), 0, (int)p.x_bytes, 0x00020000);
     tpix = kbeg + wave * BK + (lane & (BK - 1));
     timg = tpix / howo;
     const int rem = tpix - timg * howo;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
         uint2 e = {0u, 0xFFFFFFFFu};
         if (tpix < kend) {
           const int ih0 = toh * p.stride - p.pad, iw0 = tow * p.stride - p.pad;
-          e.x = (uint32_t)(((((int64_t)timg * p.H + ih0 + p.KH) * p.W + iw0 + p.KW) * p.ldx) * 4);
+          e.x = (uint32_t)(((((int64_t)timg * p.H + ih0 + p.KH) * p.W + iw0 + p.KW) * p.ldx) * ES);
           uint32_t bw = 0, m = 0;
           for (int kw = 0; kw < p.KW; ++kw) bw |= ((unsigned)(iw0 + kw) >= (unsigned)p.W ? 1u : 0u) << kw;
           const uint32_t roww = (1u << p.KW) - 1u;
@@ -204,10 +204,12 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   auto load_a_row = [&](int i) {
     if constexpr (TAB) {
       // the resource starts at the slab's first dy row and ends with the split: rows past the end are out of range -> 0
-      const int64_t left = (int64_t)(kend - k0cur) * p.ldy * 4;
+      const int64_t left = (int64_t)(kend - k0cur) * p.ldy * ES;
       const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.DY + (int64_t)k0cur * p.ldy), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0, 0x00020000);
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, a_voff[i], 0, 0));
+          (void*)(reinterpret_cast<const char*>(p.DY) + (int64_t)k0cur * p.ldy * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
+          0x00020000);
+      if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, a_voff[i], 0, 0));
+      else ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, a_voff[i], 0, 0));
       return;
     }
     const int pix = k0cur + akr + RPA * i;
@@ -232,16 +234,19 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   auto load_b_row = [&](int i) {
     if constexpr (TAB) {
       if (lin1w) {
-        const int64_t left = (int64_t)(kend - k0cur) * p.ldx * 4;
+        const int64_t left = (int64_t)(kend - k0cur) * p.ldx * ES;
         const __amdgpu_buffer_rsrc_t srd_xs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.X + (int64_t)k0cur * p.ldx), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0, 0x00020000);
-        const uint32_t voff = b_ok[0] ? (uint32_t)(((bkr + RPB * i) * p.ldx + b_ci[0]) * 4) : OOB;
-        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_xs, voff, 0, 0));
+            (void*)(reinterpret_cast<const char*>(p.X) + (int64_t)k0cur * p.ldx * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
+            0x00020000);
+        const uint32_t voff = b_ok[0] ? (uint32_t)(((bkr + RPB * i) * p.ldx + b_ci[0]) * ES) : OOB;
+        if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_xs, voff, 0, 0));
+        else rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_xs, voff, 0, 0));
         return;
       }
       const uint2 e = ptab[tab_sel][bkr + RPB * i];
       const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe((int)e.y, b_tapbit, 1);  // -1: this thread's tap leaves the image
-      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
+      if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
+      else rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
       return;
     }
     const int pix = k0cur + bkr + RPB * i;
@@ -872,9 +877,9 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
   // pixel-table loaders (wgrad_kernel<..., TAB>): tap mask in 32 bits, 31-bit byte offsets into x
   bool tab = false;
   uint32_t x_bytes_u = 0;
-  if (g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2) && d->KH * d->KW <= 32 && !bf16_io) {
+  if (g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2 || bf16_io) && d->KH * d->KW <= 32) {
     const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
-    const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4;
+    const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * (bf16_io ? 2 : 4);
     if (x_bytes < (1LL << 31)) {
       tab = true;
       x_bytes_u = (uint32_t)x_bytes;
@@ -906,7 +911,7 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
     p.mtiles = g.mtiles; p.ntiles = g.ntiles; p.splits = g.splits; p.slab_stride = g.splits > 1 ? slab : 0;
     if (tab) {
       p.x_bytes = x_bytes_u;
-      p.tab = (const uint2*)table;   // (null: the kernel builds its table slab by slab)
+      p.tab = bf16_io ? nullptr : (const uint2*)table;   // (null: the kernel builds its table slab by slab; the precomputed tables hold 4-byte offsets)
     }
   }
   const WgradP& p = pp[0];
@@ -920,7 +925,14 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p, q)
-  if (bf16_io) {
+  if (bf16_io && tab) {
+#define LAUNCHWBT(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4, true>), grid, block, 0, s, p, q)
+    if (g.bm == 128 && g.bn == 128) LAUNCHWBT(128, 128);
+    else if (g.bm == 128) LAUNCHWBT(128, 64);
+    else if (g.bn == 128) LAUNCHWBT(64, 128);
+    else LAUNCHWBT(64, 64);
+#undef LAUNCHWBT
+  } else if (bf16_io) {
 #define LAUNCHWB(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4>), grid, block, 0, s, p, q)
     if (g.bm == 128 && g.bn == 128) LAUNCHWB(128, 128);
     else if (g.bm == 128) LAUNCHWB(128, 64);

@@ -277,3 +277,40 @@ def test_bf16_storage_loss_curve_tracks_fp32_over_300_steps():
                                                                                           sm['bf16'][-1], gap))
     assert sm['f32'][-1] < sm['f32'][0] and sm['bf16'][-1] < sm['bf16'][0], 'both runs must learn the stream'
     assert gap < 0.10, gap
+
+
+@pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (2, 21, 23, 32, 64, 3, 2), (2, 16, 16, 128, 256, 1, 1), (4, 40, 40, 128, 128, 3, 1),
+                                  (1, 33, 17, 96, 64, 3, 1)])
+def test_bf16_storage_uniform_loaders_are_bit_identical_to_the_general_ones(case):
+    """Round 3: the bf16-storage GEMMs (PREC = 4) take the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders with 2-byte
+    activation offsets; as for fp32 they only change how addresses are formed: y, dx (bf16) and dw (fp32) equal bit for bit."""
+    from mmidet_hip import lib, ops
+    N, H, W, Ci, Co, k, s = case
+    d = dev()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, Ci, generator=g).to(d).to(BF)
+    w = (torch.randn(Co, k, k, Ci, generator=g) / (k * k * Ci) ** 0.5).to(d)
+    desc = ops._desc((N, H, W, Ci), Co, k, s, Ci, Co)
+    dy = torch.randn(N, desc.Ho, desc.Wo, Co, generator=g).to(d).to(BF)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.set_uniform_loaders(on)
+            y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+            nb = lib.conv_wgrad_workspace(desc)
+            ws = torch.zeros(max(nb // 4, 1), device=d)
+            nbf = lib.conv_fwd_workspace_bf16(desc)
+            wsf = torch.zeros(max(nbf // 4, 1), device=d)
+            lib.conv_fwd_bf16(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, None, wsf.data_ptr(), nbf, desc, st)
+            lib.conv_dgrad_bf16(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), None, 0, desc, st)
+            lib.conv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, desc, st)
+            torch.cuda.synchronize()
+            outs.append((y, dx, dw))
+    finally:
+        lib.set_uniform_loaders(1)
+    for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dw')):
+        assert torch.equal(a, b), what
+    # and the numbers are those of fp32 torch on the same bf16-rounded operands
+    yr = F.conv2d(nchw(x.float().cpu()), nchw(w.cpu()), None, s, k // 2)
+    close(nchw(outs[0][0].float()), yr, tol=1e-2, what='y vs torch')
