@@ -28,7 +28,8 @@ def make(kind='fourier', dropout=0.0, width=None, **kw):
         if isinstance(mod, torch.nn.Dropout):
             mod.p = dropout
     m = m.to(dev()).train()
-    ts = TrainStep(m, cfg['nc'], 128, 2, accumulate=1, **kw)
+    kw.setdefault('accumulate', 1)
+    ts = TrainStep(m, cfg['nc'], 128, 2, **kw)
     return m, ts, cfg
 
 
