@@ -338,6 +338,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the product path)'
+    # MMIDET_COMM=gloo: REHEARSAL transport (tests/test_bench_contract_gpu.py): every rank on GPU 0, rendezvous and the bucket
+    # collectives over gloo (which carries device tensors through the host; RCCL refuses two ranks on one device) -- the whole
+    # N > 1 code path of this file and of TrainStep / GradReducer on a one-GPU box.  Its numbers mean nothing.
+    rehearsal = os.environ.get('MMIDET_COMM', 'torch') == 'gloo'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ddp = world > 1 or args.ddp
@@ -351,7 +357,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        if comm_kind == 'native':
+        if comm_kind == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        elif comm_kind == 'native':
             # control plane (barriers, the max over ranks of a few floats, the 128-byte RCCL id) on gloo; the gradients go
             # through the library's own communicator on the reducer's HIP stream: no ProcessGroupNCCL, no watchdog thread
             from mmidet_hip.ddp import init_native_comm
@@ -384,7 +392,7 @@ def main():
         if 'rccl' in parts:
             from mmidet_hip.ddp import init_native_comm
             init_native_comm(0, 1)
-    ctl_dev = dev if (ddp and comm_kind != 'native') else torch.device('cpu')   # where control-plane tensors live
+    ctl_dev = dev if (ddp and comm_kind not in ('native', 'gloo')) else torch.device('cpu')   # where control-plane tensors live
 
     from mmidet_hip.train_step import TrainStep
     from models.yolo_test import Model
@@ -410,7 +418,7 @@ def main():
     ts = TrainStep(model, nc, size, bs, world_size=world, accumulate=1, graph=False)
     if ddp:
         from mmidet_hip.ddp import GradReducer
-        red = GradReducer(list(model.parameters()))
+        red = GradReducer(list(model.parameters()), comm='torch') if comm_kind == 'gloo' else GradReducer(list(model.parameters()))
         red.broadcast_parameters(model)
         if ts.ema is not None:
             red.broadcast_parameters(ts.ema.ema)      # (the EMA copy was taken from the rank-local initialisation)
@@ -576,7 +584,8 @@ def main():
                                        'whole-step hipGraph replay incl. the RCCL bucket all-reduces' if comm_kind == 'native' else
                                        'hipGraph replay of fwd+bwd, then RCCL bucket all-reduce + fused optimizer'),
                        'gradient_transport': (None if not ddp else 'mmi_allreduce_bucket (RCCL called directly on the reducer stream)'
-                                              if comm_kind == 'native' else 'torch.distributed ProcessGroupNCCL'),
+                                              if comm_kind == 'native' else 'gloo, all ranks on GPU 0 (REHEARSAL of the N > 1 code path: not a measurement)'
+                                              if comm_kind == 'gloo' else 'torch.distributed ProcessGroupNCCL'),
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
                        'host_enqueue_ms_per_step_per_rank': [round(v, 2) for v in enq_ranks],
                        'loss': [round(float(v), 5) for v in items.tolist()]},

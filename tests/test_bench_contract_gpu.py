@@ -59,3 +59,25 @@ def test_self_spawned_rank_with_the_native_transport_world1():
     j = json.loads(lines[0])
     assert j['n_gpus'] == 1 and 'mmi_allreduce_bucket' in (j['config']['gradient_transport'] or '')
     assert j['value'] > 0 and all(v == v for v in j['config']['loss'])
+
+
+@pytest.mark.parametrize('mode', ['eager', 'auto'])
+def test_two_ranks_rehearsal_on_one_gpu(mode):
+    """`python bench.py --gpus 2` end to end on a one-GPU box: the self-spawn launcher, two ranks (both on GPU 0, collectives over
+    gloo: MMIDET_COMM=gloo, a rehearsal transport), broadcast of the initial weights, warm-up, the launch-mode probe with its
+    cross-rank decision, the barrier-bracketed timed region with the max over ranks, the per-rank host-time gather and rank 0's
+    single JSON line with the whole-job aggregate -- every line of bench.py the driver's N > 1 scaling run executes except RCCL."""
+    env = dict(os.environ, MMIDET_COMM='gloo')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--workload', 's_add', '--steps', '3', '--warmup', '2',
+                        '--mode', mode, '--no-cpu-baseline', '--no-split-probe'], capture_output=True, text=True, timeout=900, cwd=REPO,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, 'rank 0 alone prints the JSON line: %r' % r.stdout[-500:]
+    j = json.loads(lines[0])
+    c = j['config']
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and c['parallelism'] == 'dp2' and c['global_batch'] == 2 * c['batch_per_gpu']
+    assert abs(j['value'] - c['global_batch'] / (j['ms_per_step'] * 1e-3)) / j['value'] < 1e-3      # whole-job aggregate
+    assert len(c['host_enqueue_ms_per_step_per_rank']) == 2 and 'REHEARSAL' in c['gradient_transport']
+    assert all(v == v and abs(v) < 1e3 for v in c['loss']), c['loss']
+    assert 'roofline' in j and 'cpu_baseline' not in j
