@@ -18,6 +18,9 @@ int sk_occupancy(int bn) {
     if (g_gemm_prec == 2 && g_uniform_loaders)
       e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 2, false, true>, 256, 0)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 2, false, true>, 256, 0);
+    else if (g_gemm_prec == 3 && g_uniform_loaders)
+      e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 3, false, true>, 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 3, false, true>, 256, 0);
     else if (g_gemm_prec == 0 && g_uniform_loaders)
       e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 128, DGRAD, true, true, 0, false, true>, 256, 0)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<128, 64, DGRAD, true, true, 0, false, true>, 256, 0);
@@ -47,7 +50,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   bool uni = false;
   // (fp32 MFMA and -- round 3 -- the six-product split, the mode reported beside the headline; the other split forms keep the
   //  cursor loaders: every (PREC, UNI) pair is another set of kernel variants to build)
-  if (vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2) && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
+  if (vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2 || g_gemm_prec == 3) && p.Kc % BK == 0 && p.KH * p.KW <= 32 && !(DGRAD && p.stride == 2 && !p.par)) {
     const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;
     const int64_t npix = (int64_t)(p.M / ((int64_t)p.P * p.Q)) * p.Hs * p.Ws;
     const int64_t a_bytes = (margin + (npix - 1) * p.lda + p.Kc) * 4;
@@ -113,7 +116,10 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       return MMI_OK;
     }
     if (g_gemm_prec == 3) {
-      if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p, q);
+      if (uni) {
+        if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI, true>), grid, block, 0, s, p, q);
+        else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI, true>), grid, block, 0, s, p, q);
+      } else if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p, q);
       else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 3, EPI>), grid, block, 0, s, p, q);
       MMI_CHECK_LAUNCH(who);
       return MMI_OK;
@@ -129,8 +135,12 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1, nz), block(256);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p, q)
-  if (vec && g_gemm_prec == 2 && uni) {
-#define LAUNCH_U2(BM_, BN_) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI, true>), grid, block, 0, s, p, q)
+  if (vec && (g_gemm_prec == 2 || g_gemm_prec == 3) && uni) {
+#define LAUNCH_U2(BM_, BN_)                                                                                                    \
+  do {                                                                                                                         \
+    if (g_gemm_prec == 2) hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 2, EPI, true>), grid, block, 0, s, p, q); \
+    else hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, true, false, 3, EPI, true>), grid, block, 0, s, p, q);                  \
+  } while (0)
     if (f.bm == 128 && f.bn == 128) LAUNCH_U2(128, 128);
     else if (f.bm == 128 && f.bn == 64) LAUNCH_U2(128, 64);
     else LAUNCH_U2(64, 64);

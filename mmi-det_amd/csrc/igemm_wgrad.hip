@@ -777,7 +777,7 @@ namespace {
 bool wgrad_uses_table(const mmi_conv_desc* d) {
   if (mmi_smallconv_supported(d)) return false;
   const WgPlan g = wgrad_plan(d);
-  if (!(g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2) && d->KH * d->KW <= 32)) return false;
+  if (!(g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2 || g_gemm_prec == 3) && d->KH * d->KW <= 32)) return false;
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0) return false;
   const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
   return (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * 4 < (1LL << 31);
@@ -877,7 +877,7 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
   // pixel-table loaders (wgrad_kernel<..., TAB>): tap mask in 32 bits, 31-bit byte offsets into x
   bool tab = false;
   uint32_t x_bytes_u = 0;
-  if (g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2 || bf16_io) && d->KH * d->KW <= 32) {
+  if (g.vec && g_uniform_loaders && (g_gemm_prec == 0 || g_gemm_prec == 2 || g_gemm_prec == 3 || bf16_io) && d->KH * d->KW <= 32) {
     const int64_t margin = ((int64_t)d->KH * d->W + d->KW) * d->ldx;
     const int64_t x_bytes = (margin + ((int64_t)d->N * d->H * d->W - 1) * d->ldx + d->Cin) * (bf16_io ? 2 : 4);
     if (x_bytes < (1LL << 31)) {
@@ -939,8 +939,12 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
     else if (g.bn == 128) LAUNCHWB(64, 128);
     else LAUNCHWB(64, 64);
 #undef LAUNCHWB
-  } else if (g.vec && g_gemm_prec == 2 && tab) {
-#define LAUNCHWT2(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2, true>), grid, block, 0, s, p, q)
+  } else if (g.vec && (g_gemm_prec == 2 || g_gemm_prec == 3) && tab) {
+#define LAUNCHWT2(BM_, BN_)                                                                                  \
+  do {                                                                                                       \
+    if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2, true>), grid, block, 0, s, p, q); \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3, true>), grid, block, 0, s, p, q);                  \
+  } while (0)
     if (g.bm == 128 && g.bn == 128) LAUNCHWT2(128, 128);
     else if (g.bm == 128) LAUNCHWT2(128, 64);
     else if (g.bn == 128) LAUNCHWT2(64, 128);

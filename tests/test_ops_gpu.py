@@ -275,7 +275,7 @@ def test_build_targets_bit_exact(tag, bs, per):
 
 @pytest.mark.parametrize('case', [(2, 20, 24, 64, 64, 3, 1), (2, 21, 23, 32, 64, 3, 2), (2, 16, 16, 128, 256, 1, 1), (4, 40, 40, 128, 128, 3, 1),
                                   (1, 33, 17, 96, 64, 3, 1)])
-@pytest.mark.parametrize('mode', [0, 2], ids=['fp32', 'bf16x6'])
+@pytest.mark.parametrize('mode', [0, 2, 3], ids=['fp32', 'bf16x6', 'bf16x9'])
 def test_uniform_loaders_are_bit_identical_to_the_general_ones(case, mode):
     """mmi_set_uniform_loaders: the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders only change how a tile's
     addresses are formed; the arithmetic and its order are those of the general cursor-based loaders, so y, dx and dw must be
