@@ -165,16 +165,19 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int row_bytes) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// x -> NP bf16 terms, each the rounded residual of the previous ones
+// x -> NP bf16 terms, each the rounded residual of the previous ones.  Written on element PAIRS: one v_cvt_pk_bf16_f32 per pair and
+// term, the residual as a packed subtract (18 VALU per float4 and three terms; element by element the compiler spent 24).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
+  f32x2 r0 = {v[0], v[1]}, r1 = {v[2], v[3]};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float r = v[i];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      t[k][i] = (__bf16)r;
-      r -= (float)t[k][i];
+  for (int k = 0; k < NP; ++k) {
+    const bf16x2 h0 = __builtin_convertvector(r0, bf16x2), h1 = __builtin_convertvector(r1, bf16x2);
+    t[k][0] = h0[0]; t[k][1] = h0[1]; t[k][2] = h1[0]; t[k][3] = h1[1];
+    if (k + 1 < NP) {
+      r0 -= __builtin_convertvector(h0, f32x2);
+      r1 -= __builtin_convertvector(h1, f32x2);
     }
   }
 }
