@@ -258,14 +258,14 @@ def test_bf16_storage_loss_curve_tracks_fp32_over_300_steps():
             torch.manual_seed(2)
             fusion_ops._seed_state.pop(dev(), None)
             fusion_ops._drop_counter[0] = 0
-            m, ts, cfg = make('fourier', dropout=0.1)
+            m, ts, cfg = make('fourier', dropout=0.1, graph=True)      # (captured step: 600 replays instead of 600 host-bound eager steps)
             m.storage = storage
             lib.set_gemm_precision(5 if storage == 'bf16' else 0)
             stream = [batch(cfg, 700 + i) for i in range(nb)]
             ls = []
             for it in range(steps):
                 loss, _ = ts.step(*stream[it % nb])
-                ls.append(loss.detach())
+                ls.append(loss.detach().clone())      # (the captured step returns its static loss tensor)
             torch.cuda.synchronize()
             curves[storage] = [float(v) for v in ls]
             assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point), storage
