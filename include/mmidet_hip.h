@@ -33,6 +33,11 @@ extern "C" {
 
 int mmi_version(void);
 const char* mmi_last_error(void);
+/* Bytes at the head of a zero-initialised workspace that hold arrival counters and are zero again after every launch (the
+ * kernels that elect a last arriver reset what they used).  kind: 0 = forward / dgrad workspace, 1 = the twin-launch form of it,
+ * 2 = weight-gradient workspace, 3 = its twin-launch form, 4 = BatchNorm backward workspace.  Test hook: a debug run checks
+ * that the region is all zero between launches (mmidet_hip/ops.py::check_counters). */
+size_t mmi_workspace_header_bytes(int kind);
 
 /* ---- conv / linear as fp32-MFMA implicit GEMM -------------------------------------------------------------------
  * Replaces nn.Conv2d forward/backward at models/common.py:114 (Conv), 764,772 (CEM convs), 333,337 (FFM 1x1),

@@ -191,6 +191,17 @@ extern "C" int mmi_set_wgrad_override(int bm, int bn, int splits) {
   return MMI_OK;
 }
 
+extern "C" size_t mmi_workspace_header_bytes(int kind) {
+  switch (kind) {
+    case 0: return WS_HEADER_BYTES;                               // forward / dgrad (one problem)
+    case 1: return 2 * WS_HEADER_BYTES;                           // forward / dgrad twin launch: [header 0 | header 1 | bodies]
+    case 2: return WG_COUNTER_BYTES;                              // weight gradient (one problem)
+    case 3: return 2 * WG_COUNTER_BYTES;                          // weight gradient twin launch
+    case 4: return (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int);   // BatchNorm backward (mmi_bn_act_bwd*)
+    default: return 0;
+  }
+}
+
 extern "C" int mmi_set_streamk_slots(int slots) {
   const int old = g_sk_slots;
   g_sk_slots = slots;

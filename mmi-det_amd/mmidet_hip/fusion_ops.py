@@ -3,7 +3,7 @@
 import torch
 from torch.autograd import Function
 
-from . import lib, ops
+from . import alloc, lib, ops
 from .lib import (EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_NONE, ConvDesc, LinearEpilogue)
 from .ops import _nrows, _stream, grad_like, rows_of, scratch, zeroed_scratch
 
@@ -40,8 +40,8 @@ class _LayerNorm(Function):
         x = x.contiguous()
         c = x.shape[-1]
         rows = _nrows(x)
-        y = torch.empty_like(x)
-        stats = torch.empty((rows, 2), dtype=x.dtype, device=x.device)
+        y = alloc.empty_like(x)
+        stats = alloc.empty((rows, 2), dtype=x.dtype, device=x.device)
         lib.layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), rows, c, eps,
                           _stream())
         ctx.save_for_backward(x, gamma, stats)
@@ -54,7 +54,7 @@ class _LayerNorm(Function):
         dy = dy.contiguous()
         c = x.shape[-1]
         rows = _nrows(x)
-        dx = torch.empty_like(x)
+        dx = alloc.empty_like(x)
         dg, db = grad_like(gamma), grad_like(ctx.beta)
         part = scratch(lib.layernorm_bwd_parts(rows) * 2 * c, x.device)
         lib.layernorm_bwd(x.data_ptr(), gamma.data_ptr(), stats.data_ptr(), dy.data_ptr(), dx.data_ptr(), part.data_ptr(),
@@ -70,7 +70,7 @@ class _Gelu(Function):
     @staticmethod
     def forward(ctx, x):
         x = x.contiguous()
-        y = torch.empty_like(x)
+        y = alloc.empty_like(x)
         lib.gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
         ctx.save_for_backward(x)
         return y
@@ -79,7 +79,7 @@ class _Gelu(Function):
     def backward(ctx, dy):
         x, = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
+        dx = alloc.empty_like(x)
         lib.gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream())
         return dx
 
@@ -92,7 +92,7 @@ class _Sigmoid(Function):
     @staticmethod
     def forward(ctx, x):
         x = x.contiguous()
-        y = torch.empty_like(x)
+        y = alloc.empty_like(x)
         lib.sigmoid_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream())
         ctx.save_for_backward(y)
         return y
@@ -101,7 +101,7 @@ class _Sigmoid(Function):
     def backward(ctx, dy):
         y, = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = torch.empty_like(y)
+        dx = alloc.empty_like(y)
         lib.sigmoid_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), _stream())
         return dx
 
@@ -115,7 +115,7 @@ class _Mul(Function):
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         assert a.shape == b.shape
-        o = torch.empty_like(a)
+        o = alloc.empty_like(a)
         lib.mul(a.data_ptr(), b.data_ptr(), o.data_ptr(), a.numel(), _stream())
         ctx.save_for_backward(a, b)
         return o
@@ -124,7 +124,7 @@ class _Mul(Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.contiguous()
-        da, db = torch.empty_like(a), torch.empty_like(b)
+        da, db = alloc.empty_like(a), alloc.empty_like(b)
         lib.mul(g.data_ptr(), b.data_ptr(), da.data_ptr(), a.numel(), _stream())
         lib.mul(g.data_ptr(), a.data_ptr(), db.data_ptr(), a.numel(), _stream())
         return da, db
@@ -140,7 +140,7 @@ class _DropoutAdd(Function):
     @staticmethod
     def forward(ctx, a, b, p, seed):
         a = a.contiguous()
-        out = torch.empty_like(a)
+        out = alloc.empty_like(a)
         bmod = 0
         if b is not None:
             b = b.contiguous()
@@ -156,7 +156,7 @@ class _DropoutAdd(Function):
         p, seed, bmod, bshape = ctx.cfg
         g = g.contiguous()
         if p > 0:
-            da = torch.empty_like(g)
+            da = alloc.empty_like(g)
             lib.dropout(g.data_ptr(), None, 0, da.data_ptr(), g.numel(), p, seed, seed_state(g.device).data_ptr(),
                         _stream())
         else:
@@ -164,7 +164,7 @@ class _DropoutAdd(Function):
         db = None
         if bshape is not None and ctx.needs_input_grad[1]:
             rows = g.numel() // bmod
-            db = torch.empty(bshape, dtype=g.dtype, device=g.device)
+            db = alloc.empty(bshape, dtype=g.dtype, device=g.device)
             part = scratch(lib.bn_bwd_parts(rows) * bmod, g.device)
             lib.colsum(da.data_ptr(), bmod, rows, bmod, part.data_ptr(), db.data_ptr(), _stream())
         return da, db, None, None
@@ -184,8 +184,8 @@ class _Attention(Function):
         b, t, c = q.shape
         assert t == 128, 'the fusion transformers always see 2*8*8 = 128 tokens'
         dk = c // heads
-        out = torch.empty_like(q)
-        probs = torch.empty((b, heads, t, t), dtype=q.dtype, device=q.device)
+        out = alloc.empty_like(q)
+        probs = alloc.empty((b, heads, t, t), dtype=q.dtype, device=q.device)
         lib.attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), b, heads, dk, c, p,
                           seed, seed_state(q.device).data_ptr() if p > 0 else None, _stream())
         ctx.save_for_backward(q, k, v, probs)
@@ -198,7 +198,7 @@ class _Attention(Function):
         heads, p, seed = ctx.cfg
         do = do.contiguous()
         b, t, c = q.shape
-        dq, dk_, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dq, dk_, dv = alloc.empty_like(q), alloc.empty_like(q), alloc.empty_like(q)
         lib.attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
                           dk_.data_ptr(), dv.data_ptr(), b, heads, c // heads, c, p, seed,
                           seed_state(q.device).data_ptr() if p > 0 else None, _stream())
@@ -314,8 +314,8 @@ class _TransformerBlock(Function):
         bsz, t, d = x.shape
         rows, hid, dev, s = bsz * t, w1.shape[0], x.device, _stream()
         sd = seed_state(dev).data_ptr() if max(ps) > 0 else None
-        new = lambda *shape: torch.empty(shape, dtype=x.dtype, device=dev)  # noqa: E731
-        ln1y, st1 = torch.empty_like(x), new(rows, 2)
+        new = lambda *shape: alloc.empty(shape, dtype=x.dtype, device=dev)  # noqa: E731
+        ln1y, st1 = alloc.empty_like(x), new(rows, 2)
         lib.layernorm_fwd(x.data_ptr(), g1.data_ptr(), b1.data_ptr(), ln1y.data_ptr(), st1.data_ptr(), rows, d, eps[0], s)
         # q, k, v are ONE projection GEMM over the (3d, d) weight pack_qkv() lays out.  Parameters that do not lie back to back
         # (a model whose parameters were moved after packing, or that never was packed) are gathered into such a matrix here:
@@ -325,17 +325,17 @@ class _TransformerBlock(Function):
         qkv = new(bsz, t, 3 * d)
         _linear_fwd(ln1y, wqkv, bqkv, qkv, rows, d, 3 * d, s)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        o, probs = torch.empty_like(x), new(bsz, heads, t, t)
+        o, probs = alloc.empty_like(x), new(bsz, heads, t, t)
         lib.attention_fwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), probs.data_ptr(), bsz, heads,
                                   d // heads, 3 * d, d, ps[0], seeds[0], sd if ps[0] > 0 else None, s)
-        x1 = torch.empty_like(x)
+        x1 = alloc.empty_like(x)
         _linear_fwd(o, wo, bo, x1, rows, d, d, s, EPI_DROPOUT_RESIDUAL, aux=x, p=ps[1], seed=seeds[1],
                     seed_dev=sd if ps[1] > 0 else None)
-        ln2y, st2 = torch.empty_like(x), new(rows, 2)
+        ln2y, st2 = alloc.empty_like(x), new(rows, 2)
         lib.layernorm_fwd(x1.data_ptr(), g2.data_ptr(), b2.data_ptr(), ln2y.data_ptr(), st2.data_ptr(), rows, d, eps[1], s)
         h, g = new(bsz, t, hid), new(bsz, t, hid)
         _linear_fwd(ln2y, w1, c1, g, rows, d, hid, s, EPI_GELU, aux_out=h)
-        x2 = torch.empty_like(x)
+        x2 = alloc.empty_like(x)
         _linear_fwd(g, w2, c2, x2, rows, hid, d, s, EPI_DROPOUT_RESIDUAL, aux=x1, p=ps[2], seed=seeds[2],
                     seed_dev=sd if ps[2] > 0 else None)
         ctx.save_for_backward(x, st1, ln1y, q, k, v, probs, o, x1, st2, ln2y, h, g, *params)
@@ -359,21 +359,21 @@ class _TransformerBlock(Function):
 
         # ---- x2 = x1 + drop(mlp2(GELU(mlp0(ln_output(x1))))) ----
         if ps[2] > 0:
-            dy2 = torch.empty_like(dx2)
+            dy2 = alloc.empty_like(dx2)
             lib.dropout(dx2.data_ptr(), None, 0, dy2.data_ptr(), dx2.numel(), ps[2], seeds[2], sd, s)
         else:
             dy2 = dx2
         wgrad(dy2, g, w2, c2, 14, hid, d)
-        dh = torch.empty_like(h)
+        dh = alloc.empty_like(h)
         _linear_dgrad(dy2, w2, dh, rows, hid, d, s, EPI_GELU_GRAD, aux=h)
         wgrad(dh, ln2y, w1, c1, 12, d, hid)
-        dln2 = torch.empty_like(x)
+        dln2 = alloc.empty_like(x)
         _linear_dgrad(dh, w1, dln2, rows, d, hid, s)
         if need[10] or need[11]:
             grads[10], grads[11] = _ln_param_grads(x1, st2, dln2, g2, b2, rows, d)
         # dx1 = dx2 + LayerNorm'(dln2); dy1 = dx1 through the out_proj dropout mask
-        dx1 = torch.empty_like(x)
-        dy1 = torch.empty_like(x) if ps[1] > 0 else None
+        dx1 = alloc.empty_like(x)
+        dy1 = alloc.empty_like(x) if ps[1] > 0 else None
         lib.layernorm_bwd_input(x1.data_ptr(), g2.data_ptr(), st2.data_ptr(), dln2.data_ptr(), dx2.data_ptr(), dx1.data_ptr(),
                                 dy1.data_ptr() if dy1 is not None else None, ps[1], seeds[1], sd if ps[1] > 0 else None,
                                 rows, d, s)
@@ -381,22 +381,22 @@ class _TransformerBlock(Function):
             dy1 = dx1
         # ---- x1 = x + drop(out_proj(attention(ln_input(x)))) ----
         wgrad(dy1, o, wo, bo, 8, d, d)
-        do = torch.empty_like(x)
+        do = alloc.empty_like(x)
         _linear_dgrad(dy1, wo, do, rows, d, d, s)
         ldq = 3 * d
-        dqkv = torch.empty((bsz, t, 3 * d), dtype=x.dtype, device=dev)
+        dqkv = alloc.empty((bsz, t, 3 * d), dtype=x.dtype, device=dev)
         dq, dk_, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
         lib.attention_bwd_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), probs.data_ptr(), do.data_ptr(), dq.data_ptr(),
                                   dk_.data_ptr(), dv.data_ptr(), bsz, heads, d // heads, ldq, d, ps[0], seeds[0],
                                   sd if ps[0] > 0 else None, s)
-        dln1 = torch.empty_like(x)
+        dln1 = alloc.empty_like(x)
         wqkv = wq if packed else torch.cat([wq, wk, wv], 0)      # (see forward)
         if all(need[2:8]) and not ops.GRAD_SLOTS:
             # the three projections' weight (and bias) gradients as ONE GEMM into one (3d, d) buffer: the parameters lie back
             # to back, their gradients may as well (each .grad is a row block of it); 3d x d output tiles instead of three
             # launches of d x d ones (the K dimension is 2048 tokens: short, so tiles are what fills the chip)
-            dwp = torch.empty((3 * d, d), dtype=wq.dtype, device=dev)
-            dbp = torch.empty(3 * d, dtype=bq.dtype, device=dev)
+            dwp = alloc.empty((3 * d, d), dtype=wq.dtype, device=dev)
+            dbp = alloc.empty(3 * d, dtype=bq.dtype, device=dev)
             dd = ConvDesc(rows, 1, 1, d, 1, 1, 3 * d, 1, 1, 1, 0, d, 3 * d)
             ops._wgrad(dqkv, 3 * d, ln1y, d, wq, dd, overlap=ops.OVERLAP_WGRAD, want_bias=True, out=(dwp, dbp))
             for i in range(3):
@@ -407,7 +407,7 @@ class _TransformerBlock(Function):
         _linear_dgrad(dqkv, wqkv, dln1, rows, d, 3 * d, s)
         if need[0] or need[1]:
             grads[0], grads[1] = _ln_param_grads(x, st1, dln1, g1, b1, rows, d)
-        dx = torch.empty_like(x)
+        dx = alloc.empty_like(x)
         lib.layernorm_bwd_input(x.data_ptr(), g1.data_ptr(), st1.data_ptr(), dln1.data_ptr(), dx1.data_ptr(), dx.data_ptr(),
                                 None, 0.0, 0, None, rows, d, s)
         if ops.OVERLAP_WGRAD:
@@ -437,7 +437,7 @@ class _PoolTokens(Function):
         rgb, ld0 = rows_of(ops.raw_cast(rgb, torch.float32))
         ir, ld1 = rows_of(ops.raw_cast(ir, torch.float32))
         n, h, w, c = rgb.shape
-        tok = torch.empty((n, 128, c), dtype=rgb.dtype, device=rgb.device)
+        tok = alloc.empty((n, 128, c), dtype=rgb.dtype, device=rgb.device)
         s = _stream()
         lib.avgpool8_fwd(rgb.data_ptr(), ld0, n, h, w, c, tok.data_ptr(), 128 * c, c, s)
         lib.avgpool8_fwd(ir.data_ptr(), ld1, n, h, w, c, tok.data_ptr() + 4 * 64 * c, 128 * c, c, s)
@@ -453,7 +453,7 @@ class _PoolTokens(Function):
         s = _stream()
         outs = []
         for i, gs in enumerate((g_rgb, g_ir)):
-            d = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+            d = alloc.empty((n, h, w, c), dtype=g.dtype, device=g.device)
             lds = 0
             if gs is not None:
                 gs, lds = rows_of(ops.raw_cast(gs, torch.float32))
@@ -479,7 +479,7 @@ class _SplitTokens(Function):
         s = _stream()
         outs = []
         for i in range(2):
-            o = torch.empty((b, 8, 8, c), dtype=tok.dtype, device=tok.device)
+            o = alloc.empty((b, 8, 8, c), dtype=tok.dtype, device=tok.device)
             lib.copy2d(tok.data_ptr() + 4 * i * 64 * c, 128 * c, o.data_ptr(), 64 * c, b, 64 * c, s)
             outs.append(o)
         return tuple(outs)
@@ -488,7 +488,7 @@ class _SplitTokens(Function):
     def backward(ctx, g0, g1):
         b, c = g0.shape[0], g0.shape[-1]
         s = _stream()
-        dt = torch.empty((b, 128, c), dtype=g0.dtype, device=g0.device)
+        dt = alloc.empty((b, 128, c), dtype=g0.dtype, device=g0.device)
         for i, g in enumerate((g0, g1)):
             g = g.contiguous()
             lib.copy2d(g.data_ptr(), 64 * c, dt.data_ptr() + 4 * i * 64 * c, 128 * c, b, 64 * c, s)
@@ -508,7 +508,7 @@ class _UpsampleAdd(Function):
         x, ldx = rows_of(ops.raw_cast(x, torch.float32))
         tok = tok.contiguous()
         n, h, w, c = x.shape
-        out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        out = alloc.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.upsample_add_fwd(x.data_ptr(), ldx, tok.data_ptr(), 64 * c, c, out.data_ptr(), c, n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
         return ops.raw_cast(out, ctx.src)
@@ -518,7 +518,7 @@ class _UpsampleAdd(Function):
         n, h, w, c = ctx.shape
         g0 = g
         g, ldg = rows_of(ops.raw_cast(g, torch.float32))
-        dtok = torch.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
+        dtok = alloc.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
         lib.upsample_add_bwd(g.data_ptr(), ldg, dtok.data_ptr(), 64 * c, c, n, h, w, c, _stream())
         return ops.raw_cast(g0, ctx.src), dtok
 
@@ -531,7 +531,7 @@ def upsample_only(tok, h, w):
     """bilinear(tok) alone, no gradient (API completeness for callers that want the FFM/GPT maps themselves)."""
     tok = tok.contiguous()
     n, c = tok.shape[0], tok.shape[-1]
-    out = torch.empty((n, h, w, c), dtype=tok.dtype, device=tok.device)
+    out = alloc.empty((n, h, w, c), dtype=tok.dtype, device=tok.device)
     lib.upsample_add_fwd(None, 0, tok.data_ptr(), 64 * c, c, out.data_ptr(), c, n, h, w, c, _stream())
     return out
 
@@ -558,7 +558,7 @@ def ffm_highpass_mul(pooled):
     """pooled (B,64,C) -> high(pooled).half() * pooled, no gradient (feeds pattenLoss only)."""
     pooled = pooled.contiguous()
     b, _, c = pooled.shape
-    out = torch.empty_like(pooled)
+    out = alloc.empty_like(pooled)
     lib.ffm_highpass(pooled.data_ptr(), out.data_ptr(), b, c, highpass_keep_mask(), _stream())
     return out
 
@@ -566,7 +566,7 @@ def ffm_highpass_mul(pooled):
 def separation_loss(m_rgb, m_ir, m_rgb_hi, m_ir_hi):
     ts = [t.contiguous() for t in (m_rgb, m_ir, m_rgb_hi, m_ir_hi)]
     b = ts[0].shape[0]
-    out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+    out = alloc.empty((), dtype=torch.float32, device=ts[0].device)
     lib.separation_loss(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), b, out.data_ptr(),
                         _stream())
     return out
@@ -580,7 +580,7 @@ def fusion_stats(in_rgb, in_ir, tok):
     n, h, w, c = a.shape
     ws = scratch(lib.fusion_stats_workspace() // 4 + 4, a.device, slot=2)
     assert ws.data_ptr() % 8 == 0
-    out = torch.empty(3, dtype=torch.float32, device=a.device)
+    out = alloc.empty(3, dtype=torch.float32, device=a.device)
     lib.fusion_stats(a.data_ptr(), lda, b.data_ptr(), ldb, tok.data_ptr(), n, h, w, c, ws.data_ptr(), out.data_ptr(),
                      _stream())
     return out

@@ -57,6 +57,7 @@ P = c_void_p
 _SIGS = {
     'mmi_version': (c_int, []),
     'mmi_last_error': (c_char_p, []),
+    'mmi_workspace_header_bytes': (c_size_t, [c_int]),
     'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
     'mmi_set_streamk_slots': (c_int, [c_int]),
     'mmi_set_tile_override': (c_int, [c_int, c_int]),

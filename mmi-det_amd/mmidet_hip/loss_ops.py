@@ -1,7 +1,7 @@
 """Detection-loss device ops over the C ABI (utils/loss.py:113-245 of the reference)."""
 import torch
 
-from . import lib
+from . import alloc, lib
 from .ops import _stream
 
 _grid_cache = {}
@@ -26,11 +26,11 @@ def build_targets_raw(targets, anchors, grids, anchor_t):
     nt = targets.shape[0]
     cap = 5 * na * nt
     dev = targets.device
-    idx = torch.empty((nl, 4, max(cap, 1)), dtype=torch.int64, device=dev)
-    tcls = torch.empty((nl, max(cap, 1)), dtype=torch.int64, device=dev)
-    tbox = torch.empty((nl, max(cap, 1), 4), dtype=torch.float32, device=dev)
-    anch = torch.empty((nl, max(cap, 1), 2), dtype=torch.float32, device=dev)
-    counts = torch.empty((nl,), dtype=torch.int32, device=dev)
+    idx = alloc.empty((nl, 4, max(cap, 1)), dtype=torch.int64, device=dev)
+    tcls = alloc.empty((nl, max(cap, 1)), dtype=torch.int64, device=dev)
+    tbox = alloc.empty((nl, max(cap, 1), 4), dtype=torch.float32, device=dev)
+    anch = alloc.empty((nl, max(cap, 1), 2), dtype=torch.float32, device=dev)
+    counts = alloc.empty((nl,), dtype=torch.int32, device=dev)
     if cap == 0:  # capacity-1 dummies keep the pointer arithmetic valid; the kernel derives strides from nt
         idx, tcls, tbox, anch = idx[:, :, :0], tcls[:, :0], tbox[:, :0], anch[:, :0]
     lib.build_targets(targets.data_ptr(), nt, anchors.data_ptr(), nl, na, _grids_dev(grids, dev).data_ptr(),

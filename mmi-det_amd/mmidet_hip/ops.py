@@ -4,7 +4,7 @@ enqueues HIP kernels of libmmidet_hip.so on the current torch stream."""
 import torch
 from torch.autograd import Function
 
-from . import lib
+from . import alloc, lib
 from .lib import ACT_LEAKY, ACT_NONE, ACT_SILU, ConvDesc  # noqa: F401
 
 _scratch = {}
@@ -33,7 +33,7 @@ def scratch(nfloats, device, slot=0, stream=None):
             # allocator would hand its memory to the next lane-stream allocation the moment the last reference drops --
             # while an earlier wgrad on the side stream may still be reducing into it.  Keep it until join_pending().
             _retired.append(buf)
-        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        buf = alloc.workspace(max(int(nfloats), 1 << 16), torch.float32, device)
         _scratch[key] = buf
     return buf
 
@@ -50,9 +50,29 @@ def zeroed_scratch(nbytes, device, stream=None, tag=0):
     if buf is None or buf.numel() < nbytes:
         if buf is not None and stream is not None and stream != _stream():
             _retired.append(buf)        # (see scratch(): a side stream may still be using it)
-        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        buf = alloc.workspace(int(nbytes), torch.uint8, device, zero=True)
         _zeroed[key] = buf
     return buf
+
+
+def check_counters():
+    """The arrival counters at the head of every zero-initialised workspace are zero between launches: each last-arriver election
+    (stream-K tiles, BatchNorm statistics folds, weight-gradient split folds) resets the counters it used.  Synchronises; raises
+    if an election was left half done.  Header sizes from the library (mmi_workspace_header_bytes)."""
+    torch.cuda.synchronize()
+    kinds = {0: 0, 'twin': 1, 'w': 2, 'twinw': 3, 'bn': 4}
+    bad = []
+    for (device, tag, stream), buf in _zeroed.items():
+        nb = lib.workspace_header_bytes(kinds[tag])
+        p = buf.data_ptr()
+        off = ((p + 255) & ~255) - p if tag in ('twin', 'twinw') else 0     # (twin_ops._aligned)
+        head = buf[off:off + min(nb, buf.numel() - off)]
+        nz = int(torch.count_nonzero(head))
+        if nz:
+            bad.append('%d non-zero counter bytes in the %r workspace of stream %#x' % (nz, tag, stream))
+    if bad:
+        raise AssertionError('arrival counters not reset: ' + '; '.join(bad))
+    return len(_zeroed)
 
 
 def conv_fwd(x, w, bias, y, part, d, s):
@@ -186,7 +206,7 @@ def grad_like(t):
         # running on the side stream -- deferred join -- which a captured step with wgrad overlap then exposed.)
         SLOT_HANDED_OUT.add(t.data_ptr())
         return slot.detach().as_strided(t.shape, t.stride())
-    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+    return alloc.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
 
 
 _wgrad_tabs = {}       # (device, geometry) -> uint8 tensor holding the layer's pixel table
@@ -217,7 +237,7 @@ def wgrad_table(d, device):
     if ent is None or ent[0].numel() < nb:
         if ent is not None:
             _retired.append(ent[0])      # a queued wgrad on a side stream may still read the smaller table (see scratch())
-        t = torch.empty(nb, dtype=torch.uint8, device=device)
+        t = alloc.workspace(nb, torch.uint8, device)
         lib.conv_wgrad_table_build(t.data_ptr(), d, cur)
         ev = torch.cuda.Event()
         ev.record()
@@ -241,7 +261,7 @@ def _wgrad(dy, lddy, x, ldx, w, d, overlap=False, want_bias=False, bias=None, ou
         assert (db is not None) == bool(want_bias)
     else:
         dw = grad_like(w)
-        db = (grad_like(bias) if bias is not None else torch.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
+        db = (grad_like(bias) if bias is not None else alloc.empty(w.shape[0], dtype=w.dtype, device=w.device)) if want_bias else None
     dbp = db.data_ptr() if want_bias else None
     k = _desc_key(d)
     nbytes = _wgrad_ws.get(k)
@@ -307,7 +327,7 @@ def raw_cast(t, dtype):
     if t.dtype == dtype:
         return t
     t, ld = rows_of(t)
-    out = torch.empty(tuple(t.shape), dtype=dtype, device=t.device)
+    out = alloc.empty(tuple(t.shape), dtype=dtype, device=t.device)
     c = t.shape[-1]
     fn = lib.cast_f32_bf16 if dtype == BF16 else lib.cast_bf16_f32
     fn(t.data_ptr(), ld, out.data_ptr(), c, _nrows(t), c, _stream())
@@ -370,7 +390,7 @@ def bn_bwd_ws(rows, c):
 
 def _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, nbt2, s):
     """conv + BatchNorm statistics (training: folded inside the conv launch) -> mean_invstd (2*cout)."""
-    mi = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+    mi = alloc.empty(2 * cout, dtype=torch.float32, device=x.device)
     bf = x.dtype == BF16
     nb, nrb = fwd_plan_bf16(d) if bf else fwd_plan(d)
     ws = zeroed_scratch(nb, x.device, s) if nb else None
@@ -458,11 +478,11 @@ class _ConvBnAct(Function):
         w = _ohwi(w)
         cout, k = w.shape[0], w.shape[2]
         d = _desc(x.shape, cout, k, stride, ldx, cout)
-        y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+        y = alloc.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
         rows = d.N * d.Ho * d.Wo
         s = _stream()
         mi = _bn_forward(x, w, y, d, cout, rows, training, eps, momentum, rmean, rvar, nbt, None, s)
-        out = _dest_view(dest, y.shape) if dest is not None else torch.empty_like(y)
+        out = _dest_view(dest, y.shape) if dest is not None else alloc.empty_like(y)
         ldo = rows_of(out)[1]
         assert out.stride(-1) == 1 and rows_of(out)[0] is out and out.dtype == y.dtype, 'the destination slice must be a strided NHWC view'
         ldr = 0
@@ -481,7 +501,7 @@ class _ConvBnAct(Function):
         cout = d.Cout
         rows = d.N * d.Ho * d.Wo
         s = _stream()
-        dy = torch.empty_like(y)
+        dy = alloc.empty_like(y)
         dgamma = grad_like(gamma)
         dbeta = grad_like(beta)
         _bn_act_bwd(y, cout, dout, ldd, None, 0, cout, mi, gamma, beta, dy, (dgamma, dbeta, None, None), rows, cout, act,
@@ -490,7 +510,7 @@ class _ConvBnAct(Function):
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
+            dx = alloc.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
             if skip and dskip is not None:
                 _dgrad_accumulate(dy, w, dx, d, dd, dskip, s)
@@ -528,11 +548,11 @@ class _DualConvBnAct(Function):
         c_ = w1.shape[0]
         cout = 2 * c_
         d = _desc(x.shape, cout, 1, 1, ldx, cout)
-        y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+        y = alloc.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
         rows = d.N * d.Ho * d.Wo
         s = _stream()
         mi = _bn_forward(x, w1, y, d, cout, rows, training, eps, momentum, rm1, rv1, nbt1, nbt2, s)
-        a = torch.empty((d.N, d.Ho, d.Wo, c_), dtype=x.dtype, device=x.device)
+        a = alloc.empty((d.N, d.Ho, d.Wo, c_), dtype=x.dtype, device=x.device)
         b = _dest_view(dest, a.shape)
         ldb = rows_of(b)[1]
         assert b.dtype == y.dtype
@@ -548,14 +568,14 @@ class _DualConvBnAct(Function):
         cout, rows, s = 2 * c_, d.N * d.Ho * d.Wo, _stream()
         da, lda = rows_of(raw_cast(da, y.dtype))
         db, ldb = rows_of(raw_cast(db, y.dtype))
-        dy = torch.empty_like(y)
+        dy = alloc.empty_like(y)
         dg1, dbt1, dg2, dbt2 = grad_like(g1), grad_like(b1), grad_like(g2), grad_like(b2)
         _bn_act_bwd(y, cout, da, lda, db, ldb, c_, mi, g1, b1, dy, (dg1, dbt1, dg2, dbt2), rows, cout, act, 0 if training else 1, s)
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0]
         d1 = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, c_, 1, 1, 1, 0, d.ldx, cout)
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and not GRAD_SLOTS and dy.dtype == torch.float32:
             # one (2c_, Cin) gradient matrix for the packed pair, each parameter's .grad a row block of it: one launch
-            flat = torch.empty(cout * d.Cin, dtype=w1.dtype, device=x.device)
+            flat = alloc.empty(cout * d.Cin, dtype=w1.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.ldx, cout)
             _wgrad(dy, cout, x, d.ldx, w1, dd, overlap=both, out=(flat, None))
             dw1, dw2 = (flat[i * c_ * d.Cin:(i + 1) * c_ * d.Cin].as_strided(w1.shape, w1.stride()) for i in range(2))
@@ -564,7 +584,7 @@ class _DualConvBnAct(Function):
             dw2 = _wgrad(dy[..., c_:], cout, x, d.ldx, w2, d1, overlap=both) if ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
+            dx = alloc.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, cout, 1, 1, 1, 0, d.Cin, cout)
             _conv_dgrad_any(dy, w1, dx, dd, s)
         if both:
@@ -675,7 +695,7 @@ class _ConvBias(Function):
             xs = tuple(x.shape)
         d = _desc(xs, cout, k, stride, ldx, cout)
         oshape = (*x.shape[:-1], cout) if w.dim() == 2 else (d.N, d.Ho, d.Wo, cout)
-        y = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        y = alloc.empty(oshape, dtype=x.dtype, device=x.device)
         if x.dtype == BF16:
             # bf16 storage: the map is bf16, this layer's OUTPUT (a Detect head: what the loss reads) is handed on as fp32
             nb = fwd_plan_bf16(d)[0]
@@ -708,7 +728,7 @@ class _ConvBias(Function):
             else:
                 dw = _wgrad(dy, lddy, x, d.ldx, w, dwd, overlap=both)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
+            dx = alloc.empty(tuple(x.shape), dtype=x.dtype, device=x.device)
             _conv_dgrad_any(dy, w, dx, dd, s)
         if want_db and db is None:
             rows = d.N * d.Ho * d.Wo
@@ -735,7 +755,7 @@ def conv_bias_act(x, w, bias, stride=1, act=ACT_SILU, residual=None):
     w = _ohwi(w)
     cout, k = w.shape[0], w.shape[2]
     d = _desc(x.shape, cout, k, stride, ldx, cout)
-    y = torch.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
+    y = alloc.empty((d.N, d.Ho, d.Wo, cout), dtype=x.dtype, device=x.device)
     ldr = 0
     if residual is not None:
         residual, ldr = rows_of(residual)
@@ -751,7 +771,7 @@ def detect_decode(levels, strides, anchor_grid, no):
     """Detect eval decode (models/yolo_test.py:57-68): levels = permuted head outputs (B,na,ny,nx,no) -> (B, sum rows, no)."""
     b, na = levels[0].shape[0], levels[0].shape[1]
     rows = [x.shape[1] * x.shape[2] * x.shape[3] for x in levels]
-    z = torch.empty((b, sum(rows), no), dtype=torch.float32, device=levels[0].device)
+    z = alloc.empty((b, sum(rows), no), dtype=torch.float32, device=levels[0].device)
     off = 0
     s = _stream()
     for i, x in enumerate(levels):
@@ -770,7 +790,7 @@ def nms(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det=300
     assert pred.dtype == torch.float32 and pred.is_cuda and pred.dim() == 3
     b, r, no = pred.shape
     nb = lib.nms_workspace(b, r, no - 5, int(multi_label))
-    ws = torch.empty(nb, dtype=torch.uint8, device=pred.device)
+    ws = alloc.empty(nb, dtype=torch.uint8, device=pred.device)
     out = torch.zeros((b, max_det, 6), dtype=torch.float32, device=pred.device)
     nout = torch.zeros(b, dtype=torch.int32, device=pred.device)
     allow = None
@@ -794,7 +814,7 @@ class _Add(Function):
     def forward(ctx, a, b, dest):
         a, lda = rows_of(a)
         b, ldb = rows_of(b)
-        out = _dest_view(dest, a.shape) if dest is not None else torch.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
+        out = _dest_view(dest, a.shape) if dest is not None else alloc.empty(tuple(a.shape), dtype=a.dtype, device=a.device)
         c = a.shape[-1]
         assert a.dtype == b.dtype == out.dtype
         (lib.add_bf16 if a.dtype == BF16 else lib.add)(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), rows_of(out)[1], _nrows(a), c, _stream())
@@ -815,7 +835,7 @@ class _Concat(Function):
     @staticmethod
     def forward(ctx, *xs):
         ctot = sum(x.shape[-1] for x in xs)
-        out = torch.empty((*xs[0].shape[:-1], ctot), dtype=xs[0].dtype, device=xs[0].device)
+        out = alloc.empty((*xs[0].shape[:-1], ctot), dtype=xs[0].dtype, device=xs[0].device)
         off = 0
         s = _stream()
         es = out.element_size()
@@ -856,10 +876,10 @@ class _Upsample2x(Function):
             assert dest is None
             if ld != c:
                 x = x.contiguous()
-            y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+            y = alloc.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
             lib.upsample2x_bf16(x.data_ptr(), y.data_ptr(), n, h, w, c, _stream())
         else:      # rows with strides on both sides: the input may be a slice of a Concat buffer, the output written into one
-            y = _dest_view(dest, (n, 2 * h, 2 * w, c)) if dest is not None else torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+            y = _dest_view(dest, (n, 2 * h, 2 * w, c)) if dest is not None else alloc.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
             lib.upsample2x_ld(x.data_ptr(), ld, y.data_ptr(), rows_of(y)[1], n, h, w, c, _stream())
         ctx.shape = (n, h, w, c)
         return (y, x_in) if skip else y
@@ -869,7 +889,7 @@ class _Upsample2x(Function):
         n, h, w, c = ctx.shape
         if g is None:
             return gskip, None, None
-        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        dx = alloc.empty((n, h, w, c), dtype=g.dtype, device=g.device)
         if g.dtype == BF16:
             g = g.contiguous()
             lib.upsample2x_bwd_bf16(g.data_ptr(), dx.data_ptr(), n, h, w, c, _stream())
@@ -895,7 +915,7 @@ class _SppPool(Function):
         ctx.src = x.dtype
         x, ld = rows_of(raw_cast(x, torch.float32))      # (bf16 storage: a P5-sized map; the pooling kernels are fp32)
         n, h, w, c = x.shape
-        out = torch.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
+        out = alloc.empty((n, h, w, 4 * c), dtype=x.dtype, device=x.device)
         lib.spp_pool_fwd(x.data_ptr(), ld, out.data_ptr(), 4 * c, n, h, w, c, _stream())
         ctx.save_for_backward(x)
         return raw_cast(out, ctx.src)
@@ -906,7 +926,7 @@ class _SppPool(Function):
         x, ld = rows_of(x)
         g, ldg = rows_of(raw_cast(g, torch.float32))
         n, h, w, c = x.shape
-        dx = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        dx = alloc.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.spp_pool_bwd(x.data_ptr(), ld, g.data_ptr(), ldg, dx.data_ptr(), c, n, h, w, c, _stream())
         return raw_cast(dx, ctx.src)
 
@@ -921,8 +941,8 @@ def u8_pair_to_nhwc(imgs_u8):
     assert imgs_u8.dtype == torch.uint8 and imgs_u8.dim() == 4 and imgs_u8.shape[1] == 6 and imgs_u8.is_cuda
     x = imgs_u8.contiguous()
     n, _, h, w = x.shape
-    rgb = torch.empty((n, h, w, 3), dtype=torch.float32, device=x.device)
-    ir = torch.empty_like(rgb)
+    rgb = alloc.empty((n, h, w, 3), dtype=torch.float32, device=x.device)
+    ir = alloc.empty_like(rgb)
     lib.u8_pair_to_nhwc(x.data_ptr(), rgb.data_ptr(), ir.data_ptr(), n, h, w, _stream())
     rgb.mmi_nhwc = ir.mmi_nhwc = True
     return rgb, ir
@@ -935,7 +955,7 @@ def nchw_to_nhwc(x):
         return x
     assert x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda
     n, c, h, w = x.shape
-    y = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+    y = alloc.empty((n, h, w, c), dtype=x.dtype, device=x.device)
     sn, sc, sh, sw = x.stride()
     lib.nchw_to_nhwc(x.data_ptr(), sn, sc, sh, sw, y.data_ptr(), n, c, h, w, _stream())
     return y
@@ -946,7 +966,7 @@ class _SpaceToDepth(Function):
     def forward(ctx, x):
         x = x.contiguous()
         n, h, w, c = x.shape
-        y = torch.empty((n, h // 2, w // 2, 4 * c), dtype=x.dtype, device=x.device)
+        y = alloc.empty((n, h // 2, w // 2, 4 * c), dtype=x.dtype, device=x.device)
         lib.space_to_depth(x.data_ptr(), y.data_ptr(), n, h, w, c, 0, _stream())
         ctx.shape = (n, h, w, c)
         return y
@@ -955,7 +975,7 @@ class _SpaceToDepth(Function):
     def backward(ctx, g):
         n, h, w, c = ctx.shape
         g = g.contiguous()
-        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        dx = alloc.empty((n, h, w, c), dtype=g.dtype, device=g.device)
         lib.space_to_depth(g.data_ptr(), dx.data_ptr(), n, h, w, c, 1, _stream())
         return dx
 
@@ -972,7 +992,7 @@ class _HeadPermute(Function):
         x = x.contiguous()
         b, ny, nx, c = x.shape
         no = c // na
-        y = torch.empty((b, na, ny, nx, no), dtype=x.dtype, device=x.device)
+        y = alloc.empty((b, na, ny, nx, no), dtype=x.dtype, device=x.device)
         lib.head_permute(x.data_ptr(), y.data_ptr(), b, na, no, ny * nx, 0, _stream())
         ctx.cfg = (b, na, no, ny, nx)
         return y
@@ -981,7 +1001,7 @@ class _HeadPermute(Function):
     def backward(ctx, g):
         b, na, no, ny, nx = ctx.cfg
         g = g.contiguous()
-        dx = torch.empty((b, ny, nx, na * no), dtype=g.dtype, device=g.device)
+        dx = alloc.empty((b, ny, nx, na * no), dtype=g.dtype, device=g.device)
         lib.head_permute(g.data_ptr(), dx.data_ptr(), b, na, no, ny * nx, 1, _stream())
         return dx, None
 
@@ -997,8 +1017,8 @@ class _SobelAdd(Function):
     def forward(ctx, r, factor, bias):
         r, ldr = rows_of(r)
         n, h, w, c = r.shape
-        t = torch.empty((n, h, w, c), dtype=r.dtype, device=r.device)
-        chansum = torch.empty((n, h, w), dtype=r.dtype, device=r.device)
+        t = alloc.empty((n, h, w, c), dtype=r.dtype, device=r.device)
+        chansum = alloc.empty((n, h, w), dtype=r.dtype, device=r.device)
         f = factor.reshape(-1).contiguous()
         lib.sobel_add_fwd(r.data_ptr(), ldr, f.data_ptr(), bias.data_ptr(), chansum.data_ptr(), t.data_ptr(), c, n, h, w, c,
                           _stream())
@@ -1011,9 +1031,9 @@ class _SobelAdd(Function):
         chansum, f = ctx.saved_tensors
         n, h, w, c, fshape = ctx.cfg
         dt, ldd = rows_of(dt)
-        dr = torch.empty((n, h, w, c), dtype=dt.dtype, device=dt.device)
-        df = torch.empty(c, dtype=dt.dtype, device=dt.device)
-        db = torch.empty(c, dtype=dt.dtype, device=dt.device)
+        dr = alloc.empty((n, h, w, c), dtype=dt.dtype, device=dt.device)
+        df = alloc.empty(c, dtype=dt.dtype, device=dt.device)
+        db = alloc.empty(c, dtype=dt.dtype, device=dt.device)
         nbytes = lib.sobel_add_bwd_workspace(n, h, w, c)
         ws = scratch(nbytes // 4 + 4, dt.device, slot=5)
         lib.sobel_add_bwd(dt.data_ptr(), ldd, chansum.data_ptr(), f.data_ptr(), dr.data_ptr(), c, df.data_ptr(),
@@ -1048,8 +1068,8 @@ class _CemFused(Function):
         rows = n * h * w
         nblk = lib.cem_blocks(n, h, w)
         f = factor.reshape(-1).contiguous()
-        mi2 = torch.empty(48, dtype=torch.float32, device=dev)
-        mi3 = torch.empty(6, dtype=torch.float32, device=dev)
+        mi2 = alloc.empty(48, dtype=torch.float32, device=dev)
+        mi3 = alloc.empty(6, dtype=torch.float32, device=dev)
         if training:
             part = scratch((nblk + 64) * 2 * 24, dev)
             lib.cem_conv2_stats(x.data_ptr(), ldx, w2.data_ptr(), part.data_ptr(), n, h, w, s)
@@ -1057,10 +1077,10 @@ class _CemFused(Function):
         else:
             lib.bn_eval_stats(rm2.data_ptr(), rv2.data_ptr(), 24, eps, mi2.data_ptr(), s)
         keep = any(ctx.needs_input_grad)      # (grad mode itself is off inside forward)
-        y2 = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
-        t = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
-        cs = torch.empty((n, h, w), dtype=torch.float32, device=dev) if keep else None
-        y3 = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+        y2 = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
+        t = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
+        cs = alloc.empty((n, h, w), dtype=torch.float32, device=dev) if keep else None
+        y3 = alloc.empty((n, h, w, 3), dtype=torch.float32, device=dev)
         part3 = scratch((nblk + 64) * 2 * 3, dev, slot=6) if training else None
         lib.cem_fused_fwd(x.data_ptr(), ldx, w2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), f.data_ptr(), sbias.data_ptr(),
                           w3.data_ptr(), y2.data_ptr() if keep else None, t.data_ptr() if keep else None, cs.data_ptr() if keep else None,
@@ -1069,7 +1089,7 @@ class _CemFused(Function):
             lib.bn_finalize(part3.data_ptr(), nblk, rows, 3, eps, momentum, rm3.data_ptr(), rv3.data_ptr(), nbt3.data_ptr(), mi3.data_ptr(), s)
         else:
             lib.bn_eval_stats(rm3.data_ptr(), rv3.data_ptr(), 3, eps, mi3.data_ptr(), s)
-        out = torch.empty_like(y3)
+        out = alloc.empty_like(y3)
         lib.bn_act_fwd(y3.data_ptr(), 3, mi3.data_ptr(), g3.data_ptr(), b3.data_ptr(), x.data_ptr(), ldx, out.data_ptr(), 3, rows, 3,
                        ACT_LEAKY, s)
         if keep:
@@ -1085,7 +1105,7 @@ class _CemFused(Function):
         dev, s = x.device, _stream()
         rows, frozen = n * h * w, 0 if training else 1
         # BN3 + LeakyReLU (+ the residual, whose gradient is dout itself)
-        dy3 = torch.empty_like(y3)
+        dy3 = alloc.empty_like(y3)
         dg3, db3 = grad_like(g3), grad_like(b3)
         _bn_act_bwd(y3, 3, dout, ldd, None, 0, 3, mi3, g3, b3, dy3, (dg3, db3, None, None), rows, 3, ACT_LEAKY, frozen, s)
         # conv3: t (24) -> y3 (3)
@@ -1096,8 +1116,8 @@ class _CemFused(Function):
         # stream, where nothing is waiting for either.  Measured in the step (three interleaved pairs): 122.46 vs 122.55 ms, i.e. nothing --
         # MMIDET_CEM_WGRAD_LATE=1 keeps the variant, the default is the original order.
         dw3 = None if CEM_WGRAD_LATE else _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
-        dr = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
-        df = torch.empty(24, dtype=torch.float32, device=dev)
+        dr = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev)
+        df = alloc.empty(24, dtype=torch.float32, device=dev)
         dsb = grad_like(sbias)
         if CEM_BWD_FUSED:
             # conv3's input gradient and the stencil bank's backward in one kernel: dt never reaches HBM (csrc/cem.hip)
@@ -1108,14 +1128,14 @@ class _CemFused(Function):
                             ws.data_ptr(), *((y2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr())
                                              if CEM_BWD_BN else (None,) * 5), n, h, w, s)
         else:
-            dt = torch.empty((n, h, w, 24), dtype=torch.float32, device=dev)
+            dt = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev)
             conv_dgrad(dy3, w3, dt, ConvDesc(n, h, w, 24, h, w, 3, 3, 3, 1, 1, 24, 3), s)
             nbytes = lib.sobel_add_bwd_workspace(n, h, w, 24)
             ws = scratch(nbytes // 4 + 4, dev, slot=5)
             lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr.data_ptr(), 24, df.data_ptr(), dsb.data_ptr(),
                               ws.data_ptr(), n, h, w, 24, s)
         # BN2 + LeakyReLU
-        dy2 = torch.empty_like(y2)
+        dy2 = alloc.empty_like(y2)
         dg2, db2 = grad_like(g2), grad_like(b2)
         if CEM_BWD_FUSED and CEM_BWD_BN:     # the reduction came out of cem_bwd_mid: fold its partials, then the apply pass
             lib.bn_act_bwd_apply(y2.data_ptr(), 24, dr.data_ptr(), 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr(),
@@ -1130,7 +1150,7 @@ class _CemFused(Function):
             dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+            dx = alloc.empty((n, h, w, 3), dtype=torch.float32, device=dev)
             conv_dgrad(dy2, w2, dx, ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, 3, 24), s)
             lib.add(dx.data_ptr(), 3, dout.data_ptr(), ldd, dx.data_ptr(), 3, rows, 3, s)
         if OVERLAP_WGRAD:

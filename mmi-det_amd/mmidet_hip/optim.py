@@ -10,7 +10,7 @@ import math
 import numpy as np
 import torch
 
-from . import lib
+from . import alloc, lib
 from .ops import _stream
 
 _REC = np.dtype([('p', '<u8'), ('g', '<u8'), ('buf', '<u8'), ('ema', '<u8'), ('n', '<i8'), ('group', '<i4'), ('flags', '<i4')])
@@ -120,7 +120,7 @@ class FusedSGDEMA:
             self._part_chunks[name] = (torch.from_numpy(arr).to(self.device) if len(sel) else None, len(sel))
         nbytes = rec.view(np.uint8).reshape(-1).size
         self._recs_stage = _Staging(nbytes, self.device)
-        self._recs_dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._recs_dev = alloc.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _refresh_grads(self, part=None):
         """Gradients are fresh tensors every eager step (AccumulateGrad steals them); re-point the table when they move.

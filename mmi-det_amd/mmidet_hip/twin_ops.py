@@ -12,7 +12,7 @@ producers in place and read back as views, as in the single-lane form (ops._CatA
 import torch
 from torch.autograd import Function
 
-from . import lib, ops
+from . import alloc, lib, ops
 from .lib import ConvDesc
 from .ops import _stream, grad_like, scratch, zeroed_scratch
 
@@ -73,12 +73,12 @@ def conv_bn_fwd2(x, ldx, lsx, wa, wb, y, cout, k, stride, bns, eps, momentum, tr
     cin = x.shape[4]
     d = ops._desc((n, h, w, cin), cout, k, stride, ldx, 2 * cout)
     dev = x.device
-    mi = torch.empty(4 * cout, dtype=torch.float32, device=dev)
+    mi = alloc.empty(4 * cout, dtype=torch.float32, device=dev)
     if not training:
         for g, wt in enumerate((wa, wb)):
             ops.conv_fwd_raw(x.data_ptr() + 4 * g * lsx, wt.data_ptr(), y.data_ptr() + 4 * g * cout, d, dev, s)
             rm, rv = bns[g][0], bns[g][1]
-            tmp = torch.empty(2 * cout, dtype=torch.float32, device=dev)
+            tmp = alloc.empty(2 * cout, dtype=torch.float32, device=dev)
             lib.bn_eval_stats(rm.data_ptr(), rv.data_ptr(), cout, eps, tmp.data_ptr(), s)
             mi[g * cout:(g + 1) * cout].copy_(tmp[:cout])
             mi[2 * cout + g * cout:2 * cout + (g + 1) * cout].copy_(tmp[cout:])
@@ -188,10 +188,10 @@ class _TwinConvBnAct(Function):
         s = _stream()
         pad = k // 2
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-        y = torch.empty((n, ho, wo, 2, cout), dtype=x.dtype, device=x.device)
+        y = alloc.empty((n, ho, wo, 2, cout), dtype=x.dtype, device=x.device)
         mi, d = conv_bn_fwd2(x, ldx, lsx, wa, wb, y, cout, k, stride, ((rma, rva, nbta, None), (rmb, rvb, nbtb, None)), eps, momentum,
                              training, s)
-        out = dest.t if dest is not None else torch.empty_like(y)
+        out = dest.t if dest is not None else alloc.empty_like(y)
         assert tuple(out.shape) == tuple(y.shape), 'the destination view %s does not fit the output %s' % (tuple(out.shape), tuple(y.shape))
         ldo, lso = layout(out)
         rows = n * ho * wo
@@ -218,7 +218,7 @@ class _TwinConvBnAct(Function):
         s = _stream()
         ldd, lsd = layout(dout)
         ldx, lsx = layout(x)
-        dy = torch.empty_like(y)
+        dy = alloc.empty_like(y)
         dgs = (grad_like(ga), grad_like(gb))
         dbs = (grad_like(ba), grad_like(bb))
         m = _bn_map((ga, gb), (ba, bb), cout, cout, cout, lsd, 0, dgs, dbs)
@@ -233,7 +233,7 @@ class _TwinConvBnAct(Function):
             dwa, dwb = wgrad2(dy, 0, 2 * cout, cout, x, ldx, lsx, wa, wb, cout, k, stride, (n, h, w, cin), both)
         dx = None
         if need_x:
-            dx = torch.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)
+            dx = alloc.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)
             dgrad2(dy, cout, wa, wb, dx, d, dskip if skip else None, s)
         if both:
             ops._join_side(x.device)
@@ -262,10 +262,10 @@ class _TwinDualConvBnAct(Function):
         c_ = w1a.shape[0]
         n, h, w = x.shape[:3]
         s = _stream()
-        y = torch.empty((n, h, w, 2, 2 * c_), dtype=x.dtype, device=x.device)
+        y = alloc.empty((n, h, w, 2, 2 * c_), dtype=x.dtype, device=x.device)
         mi, d = conv_bn_fwd2(x, ldx, lsx, w1a, w1b, y, 2 * c_, 1, 1, ((rma, rva, nbt1a, nbt2a), (rmb, rvb, nbt1b, nbt2b)), eps, momentum,
                              training, s)
-        a = torch.empty((n, h, w, 2, c_), dtype=x.dtype, device=x.device)
+        a = alloc.empty((n, h, w, 2, c_), dtype=x.dtype, device=x.device)
         b = cat.t[..., c_:]
         ldb, lsb = layout(b)
         rows = n * h * w
@@ -285,7 +285,7 @@ class _TwinDualConvBnAct(Function):
         ldx, lsx = layout(x)
         lda, lsa = layout(da)
         ldb, lsb = layout(db)
-        dy = torch.empty_like(y)
+        dy = alloc.empty_like(y)
         gs, bs = (g1a, g2a, g1b, g2b), (b1a, b2a, b1b, b2b)
         dgs, dbs = tuple(grad_like(t) for t in gs), tuple(grad_like(t) for t in bs)
         m = _bn_map(gs, bs, c_, 2 * c_, c_, lsa, lsb, dgs, dbs)
@@ -302,13 +302,13 @@ class _TwinDualConvBnAct(Function):
         else:
             # cv1 | cv2 are one (2c_, Cin) matrix per lane (ops.pack_pair), and so is their gradient: ONE twin launch with 2c_
             # output rows; each parameter's .grad is a row block of the lane's buffer
-            fa, fb = (torch.empty(2 * c_ * cin, dtype=w1a.dtype, device=x.device) for _ in range(2))
+            fa, fb = (alloc.empty(2 * c_ * cin, dtype=w1a.dtype, device=x.device) for _ in range(2))
             wgrad2(dy, 0, 4 * c_, 2 * c_, x, ldx, lsx, w1a, w1b, 2 * c_, 1, 1, (n, h, w, cin), both, out=(fa, fb))
             dw1a, dw2a = (fa[i * c_ * cin:(i + 1) * c_ * cin].as_strided(w1a.shape, w1a.stride()) for i in range(2))
             dw1b, dw2b = (fb[i * c_ * cin:(i + 1) * c_ * cin].as_strided(w1b.shape, w1b.stride()) for i in range(2))
         dx = None
         if need_x:
-            dx = torch.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)
+            dx = alloc.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)
             dgrad2(dy, 2 * c_, w1a, w1b, dx, d, None, s)
         if both:
             ops._join_side(x.device)
@@ -334,7 +334,7 @@ class _TwinSppPool(Function):
     def forward(ctx, x):
         x = dense(x)
         n, h, w, _, c = x.shape
-        out = torch.empty((n, h, w, 2, 4 * c), dtype=x.dtype, device=x.device)
+        out = alloc.empty((n, h, w, 2, 4 * c), dtype=x.dtype, device=x.device)
         s = _stream()
         for g in range(2):
             lib.spp_pool_fwd(x.data_ptr() + 4 * g * c, 2 * c, out.data_ptr() + 16 * g * c, 8 * c, n, h, w, c, s)
@@ -346,7 +346,7 @@ class _TwinSppPool(Function):
         x, = ctx.saved_tensors
         n, h, w, _, c = x.shape
         ldg, lsg = layout(g)
-        dx = torch.empty_like(x)
+        dx = alloc.empty_like(x)
         s = _stream()
         for q in range(2):
             lib.spp_pool_bwd(x.data_ptr() + 4 * q * c, 2 * c, g.data_ptr() + 4 * q * lsg, ldg, dx.data_ptr() + 4 * q * c, 2 * c, n, h, w, c, s)
@@ -365,7 +365,7 @@ class _TwinSpaceToDepth(Function):
     def forward(ctx, xa, xb):
         xa, xb = xa.contiguous(), xb.contiguous()
         n, h, w, c = xa.shape
-        y = torch.empty((n, h // 2, w // 2, 2, 4 * c), dtype=xa.dtype, device=xa.device)
+        y = alloc.empty((n, h // 2, w // 2, 2, 4 * c), dtype=xa.dtype, device=xa.device)
         s = _stream()
         for g, t in enumerate((xa, xb)):
             lib.space_to_depth_ld(t.data_ptr(), y.data_ptr() + 16 * g * c, n, h, w, c, 8 * c, 0, s)
@@ -382,7 +382,7 @@ class _TwinSpaceToDepth(Function):
             if not ctx.needs_input_grad[q]:
                 outs.append(None)
                 continue
-            dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+            dx = alloc.empty((n, h, w, c), dtype=g.dtype, device=g.device)
             lib.space_to_depth_ld(g.data_ptr() + 4 * q * lsg, dx.data_ptr(), n, h, w, c, ldg, 1, s)
             outs.append(dx)
         return tuple(outs)
@@ -402,7 +402,7 @@ class _TwinPoolTokens(Function):
         ctx.set_materialize_grads(False)
         ld, ls = layout(x)
         n, h, w, _, c = x.shape
-        tok = torch.empty((n, 128, c), dtype=x.dtype, device=x.device)
+        tok = alloc.empty((n, 128, c), dtype=x.dtype, device=x.device)
         s = _stream()
         for g in range(2):
             lib.avgpool8_fwd(x.data_ptr() + 4 * g * ls, ld, n, h, w, c, tok.data_ptr() + 4 * g * 64 * c, 128 * c, c, s)
@@ -416,7 +416,7 @@ class _TwinPoolTokens(Function):
             return gx, None
         g = g.contiguous()
         s = _stream()
-        d = torch.empty((n, h, w, 2, c), dtype=g.dtype, device=g.device)
+        d = alloc.empty((n, h, w, 2, c), dtype=g.dtype, device=g.device)
         lds = lss = 0
         if gx is not None:
             lds, lss = layout(gx)
@@ -441,7 +441,7 @@ class _TwinUpsampleAdd(Function):
     def forward(ctx, x, tok_a, tok_b):
         ld, ls = layout(x)
         n, h, w, _, c = x.shape
-        out = torch.empty((n, h, w, 2, c), dtype=x.dtype, device=x.device)
+        out = alloc.empty((n, h, w, 2, c), dtype=x.dtype, device=x.device)
         s = _stream()
         for g, tok in enumerate((tok_a.contiguous(), tok_b.contiguous())):
             lib.upsample_add_fwd(x.data_ptr() + 4 * g * ls, ld, tok.data_ptr(), 64 * c, c, out.data_ptr() + 4 * g * c, 2 * c, n, h, w, c, s)
@@ -455,7 +455,7 @@ class _TwinUpsampleAdd(Function):
         s = _stream()
         dts = []
         for q in range(2):
-            dt = torch.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
+            dt = alloc.empty((n, 8, 8, c), dtype=g.dtype, device=g.device)
             lib.upsample_add_bwd(g.data_ptr() + 4 * q * lsg, ldg, dt.data_ptr(), 64 * c, c, n, h, w, c, s)
             dts.append(dt)
         return g, dts[0], dts[1]
@@ -473,7 +473,7 @@ class _TwinAddLanes(Function):
     def forward(ctx, x, dest):
         ld, ls = layout(x)
         n, h, w, _, c = x.shape
-        out = ops._dest_view(dest, (n, h, w, c)) if dest is not None else torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        out = ops._dest_view(dest, (n, h, w, c)) if dest is not None else alloc.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         lib.add(x.data_ptr(), ld, x.data_ptr() + 4 * ls, ld, out.data_ptr(), ops.rows_of(out)[1], n * h * w, c, _stream())
         return out
 
@@ -495,7 +495,7 @@ class _TwinStack(Function):
     @staticmethod
     def forward(ctx, a, b):
         n, h, w, c = a.shape
-        out = torch.empty((n, h, w, 2, c), dtype=a.dtype, device=a.device)
+        out = alloc.empty((n, h, w, 2, c), dtype=a.dtype, device=a.device)
         s = _stream()
         for g, t in enumerate((a, b)):
             t, ld = ops.rows_of(t)
@@ -522,7 +522,7 @@ class _TwinLanes(Function):
     @staticmethod
     def backward(ctx, ga, gb):
         n, h, w, c = ga.shape
-        out = torch.empty((n, h, w, 2, c), dtype=ga.dtype, device=ga.device)
+        out = alloc.empty((n, h, w, 2, c), dtype=ga.dtype, device=ga.device)
         s = _stream()
         for q, t in enumerate((ga, gb)):
             t, ld = ops.rows_of(t)

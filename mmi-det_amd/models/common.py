@@ -14,6 +14,7 @@ import math
 import torch
 import torch.nn as nn
 
+from mmidet_hip import alloc
 from mmidet_hip import fusion_ops as F2
 from mmidet_hip import ops
 from mmidet_hip import twin_ops as T2
@@ -140,7 +141,7 @@ class C3(nn.Module):
         # cv1 | cv2 as one GEMM; the concat buffer is written in place by its two producers (models/common.py:650 without the copy)
         a, b = self.cv1, self.cv2
         c_ = a.conv.weight.shape[0]
-        cat = ops.Dest(torch.empty((*x.shape[:-1], 2 * c_), dtype=x.dtype, device=x.device))
+        cat = ops.Dest(alloc.empty((*x.shape[:-1], 2 * c_), dtype=x.dtype, device=x.device))
         h, b_out = ops.dual_conv_bn_act(x, a.conv.weight, b.conv.weight, a.bn.weight, a.bn.bias, b.bn.weight, b.bn.bias,
                                         a.bn.running_mean, a.bn.running_var, a.bn.num_batches_tracked,
                                         b.bn.num_batches_tracked, a._act_id(), a.bn.training, a.bn.eps, a.bn.momentum,
@@ -159,7 +160,7 @@ class C3(nn.Module):
         """Both backbones' C3 on a twin tensor: cv1|cv2 of both lanes as one GEMM, the lanes' concat buffers side by side
         (N,H,W,2,2c_) and written in place by their producers, cv3 of both lanes as one GEMM."""
         c_ = self.cv1.conv.weight.shape[0]
-        cat = torch.empty((*x.shape[:3], 2, 2 * c_), dtype=x.dtype, device=x.device)
+        cat = alloc.empty((*x.shape[:3], 2, 2 * c_), dtype=x.dtype, device=x.device)
         h, b_out = T2.dual_conv_bn_act2(x, self, other, ops.Dest(cat))
         last = len(self.m) - 1
         for i, (ba, bb) in enumerate(zip(self.m, other.m)):

@@ -16,6 +16,7 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
+from mmidet_hip import alloc
 from mmidet_hip import fusion_ops as F2
 from mmidet_hip import ops
 from mmidet_hip import twin_ops as T2
@@ -359,7 +360,7 @@ class Model(nn.Module):
                     h, w = (h + 2 * (ks // 2) - ks) // st + 1, (w + 2 * (ks // 2) - ks) // st + 1
                 elif isinstance(m, Upsample2x):
                     h, w = 2 * h, 2 * w
-                holder = cat_bufs[k] = ops.Dest(torch.empty((n, h, w, self._cat_total[k]), dtype=torch.float32, device=dev))
+                holder = cat_bufs[k] = ops.Dest(alloc.empty((n, h, w, self._cat_total[k]), dtype=torch.float32, device=dev))
             return (holder, off)
 
         def twin_of(v):
@@ -493,18 +494,35 @@ class Model(nn.Module):
     def _pack_for_twin(self):
         """C3's cv1 | cv2 run as one GEMM -- and the two backbones' C3 as one twin launch -- only when their parameters share
         buffers (ops.pack_pair: same Parameters, state_dict keys and values).  TrainStep packs before it builds its optimizer;
-        a caller that drives the model itself (the reference's train.py / test.py) gets the packing at its first forward on the
-        device.  Never while a data-parallel reducer holds gradient slots keyed on the parameter addresses."""
-        w = next((p for p in self.parameters() if p.is_cuda), None)
-        key = (w.data_ptr(), w._version) if w is not None else None
-        if key is None or getattr(self, '_pack_key', None) == key or ops.GRAD_SLOTS or torch.cuda.is_current_stream_capturing():
+        a caller that drives the model itself (the reference's train.py) gets the packing at the first TRAINING forward on the
+        device.  Re-seating parameters is a side effect only the owner of their addresses may trigger, so it never happens for
+        a model that is not being trained (eval mode, or no parameter that requires a gradient: the EMA copy, whose addresses
+        FusedSGDEMA's pointer table and ModelEMA's pair list have cached -- ModelEMA packs its copy itself, at construction),
+        and never while a data-parallel reducer holds gradient slots keyed on the parameter addresses.  An unpacked model runs
+        the same kernels on the lane / gathered forms."""
+        if not self.training or ops.GRAD_SLOTS or torch.cuda.is_current_stream_capturing():
             return
+        first = last = None
+        for p in self.parameters():                                # placement key: no _version (every optimizer step bumps it)
+            if p.is_cuda:
+                last = p
+                if first is None:
+                    first = p
+        if first is None or not first.requires_grad:
+            return
+        key = (first.data_ptr(), last.data_ptr())
+        if getattr(self, '_pack_key', None) == key:
+            return
+        self.pack_parameters()
+        self._pack_key = (first.data_ptr(), last.data_ptr())
+
+    def pack_parameters(self):
+        """Explicit form of the above for whoever owns the parameter addresses (TrainStep, ModelEMA for its copy)."""
         if ops.PACK_C3:
             ops.pack_pair(self)
         if os.environ.get('MMIDET_PACK_QKV', '1') != '0':
-            F2.pack_qkv(self)          # q/k/v projections of the fusion transformers as one GEMM each way (as TrainStep does)
-        w = next(p for p in self.parameters() if p.is_cuda)
-        self._pack_key = (w.data_ptr(), w._version)
+            F2.pack_qkv(self)          # q/k/v projections of the fusion transformers as one GEMM each way
+        return self
 
     def _single(self, v):
         """Inputs of a single-lane layer: Lane placeholders become (N,H,W,C) views of their twin tensor (one autograd node per

@@ -13,7 +13,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from mmidet_hip import lib, loss_ops
+from mmidet_hip import alloc, lib, loss_ops
 from mmidet_hip.ops import _stream, scratch
 from utils.torch_utils import is_parallel
 
@@ -43,11 +43,11 @@ class _DetectLoss(Function):
         dev = preds[0].device
         bs = preds[0].shape[0]
         idx, tcls, tbox, anch, counts, cap = loss_ops.build_targets_raw(targets, anchors, grids, anchor_t)
-        dps = [torch.empty_like(p) for p in preds]
+        dps = [alloc.empty_like(p) for p in preds]
         total = sum(p.numel() // p.shape[-1] for p in preds)
         nbytes = lib.detect_loss_workspace(nl, total, cap)
         ws = scratch(nbytes // 4 + 4, dev, slot=3)
-        out5 = torch.empty(5, dtype=torch.float32, device=dev)
+        out5 = alloc.empty(5, dtype=torch.float32, device=dev)
         pp = (ctypes.c_void_p * nl)(*[p.data_ptr() for p in preds])
         dpp = (ctypes.c_void_p * nl)(*[d.data_ptr() for d in dps])
         gh = (ctypes.c_int32 * (2 * nl))(*[v for g in grids for v in g])
@@ -66,7 +66,7 @@ class _DetectLoss(Function):
         outs = []
         g = g.contiguous()
         for dp in ctx.saved_tensors:
-            o = torch.empty_like(dp)
+            o = alloc.empty_like(dp)
             lib.scale(dp.data_ptr(), g.data_ptr(), o.data_ptr(), dp.numel(), _stream())
             outs.append(o)
         return (None, None, None, *outs)

@@ -60,6 +60,11 @@ class ModelEMA:
         self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
         for p in self.ema.parameters():
             p.requires_grad_(False)
+        # deepcopy clones every parameter on its own, so a packed model's copy is unpacked again.  Pack the copy HERE, while
+        # nobody has cached its addresses yet (FusedSGDEMA's pointer table, _pairs below); a forward of the copy never re-seats
+        # anything (models/yolo_test.py::_pack_for_twin).
+        if hasattr(self.ema, 'pack_parameters') and any(p.is_cuda for p in self.ema.parameters()):
+            self.ema.pack_parameters()
         self._pairs = None
 
     def update(self, model):

@@ -15,6 +15,25 @@ CFG_DIR = os.path.join(PKG, 'models', 'transformer')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Poison mode for the GPU suite (mmidet_hip/alloc.py): every output / workspace is born as 0xFF bytes (NaN / -1) between
+    # guard zones, so an element no kernel stored, or a store outside an output, fails the test that caused it instead of
+    # hiding behind whatever a recycled block held.  Must be set before mmidet_hip is imported.  MMIDET_POISON=0 switches off.
+    expr = config.getoption('markexpr', '') or ''
+    if 'gpu' in expr and 'not gpu' not in expr:
+        os.environ.setdefault('MMIDET_POISON', '1')
+
+
+@pytest.fixture(autouse=True)
+def _poison_checks(request):
+    """After every GPU test: the guard zones of everything allocated during the test are intact (no out-of-range store) and
+    every workspace's arrival counters are back at zero (no last-arriver election left half done)."""
+    yield
+    if request.node.get_closest_marker('gpu') is None or 'mmidet_hip.alloc' not in sys.modules:
+        return
+    from mmidet_hip import alloc, ops
+    if alloc.POISON:
+        alloc.check_guards()
+        ops.check_counters()
 
 
 def tiny_cfg(kind):

@@ -466,3 +466,60 @@ def test_one_wgrad_stream_per_lane_is_the_same_training(monkeypatch):
     torch.cuda.synchronize()
     for (k, a), (_, bb) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, bb), k
+
+
+def test_ema_forward_between_steps_does_not_move_the_ema_weights():
+    """a device forward of the EMA copy (the per-epoch test.test(model=ema.ema) of train.py:840-855) must
+    not re-seat its parameters -- FusedSGDEMA's pointer table and ModelEMA's pair list hold their addresses.  N steps, an
+    EMA forward, M more steps == the same run without the forward, bit for bit, and the addresses never change."""
+    m1, ts1, cfg = make()
+    m2, ts2, _ = make()
+    ptr0 = {k: v.data_ptr() for k, v in ts1.ema.ema.state_dict().items()}
+    batches = [batch(cfg, 40 + i) for i in range(5)]
+    for i, (imgs, tg) in enumerate(batches):
+        ts1.step(imgs, tg)
+        ts2.step(imgs, tg)
+        if i == 1:
+            x = imgs.float() / 255
+            with torch.no_grad():
+                out = ts1.ema.ema(x[:, :3], x[:, 3:])
+            assert torch.isfinite(out[0][0]).all()
+            assert {k: v.data_ptr() for k, v in ts1.ema.ema.state_dict().items()} == ptr0
+    torch.cuda.synchronize()
+    e1, e2 = ts1.ema.ema.state_dict(), ts2.ema.ema.state_dict()
+    for k in e1:
+        assert torch.equal(e1[k], e2[k]), k
+    # and the EMA really moved away from its initial copy of the weights (the kernel writes into the live tensors)
+    w = 'model.1.conv.weight'
+    assert not torch.equal(e1[w], m1.state_dict()[w])
+
+
+def test_model_ema_packs_its_copy_at_construction():
+    """The reference's own ModelEMA call order (train.py: ModelEMA(model) before the first forward): the copy is packed when it
+    is made, the training model at its first training forward; an eval forward of either never re-seats a parameter."""
+    from utils.torch_utils import ModelEMA
+    from models.yolo_test import Model
+    from oracle import portable_init
+    cfg = tiny_cfg('fourier')
+    m = Model(copy.deepcopy(cfg))
+    m.load_state_dict(portable_init.fill_(m.state_dict()))
+    m = m.to(dev()).train()
+    ema = ModelEMA(m)
+    c3 = next(mod for mod in ema.ema.modules() if type(mod).__name__ == 'C3')
+    from mmidet_hip.ops import back_to_back
+    assert back_to_back(c3.cv1.conv.weight.data, c3.cv2.conv.weight.data)
+    ptr0 = [p.data_ptr() for p in ema.ema.parameters()]
+    imgs, _ = batch(cfg, 3)
+    x = imgs.float() / 255
+    with torch.no_grad():
+        ema.ema(x[:, :3], x[:, 3:])
+    assert [p.data_ptr() for p in ema.ema.parameters()] == ptr0
+    m.eval()
+    ptrm = [p.data_ptr() for p in m.parameters()]
+    with torch.no_grad():
+        m(x[:, :3], x[:, 3:])
+    assert [p.data_ptr() for p in m.parameters()] == ptrm          # eval forward: no packing side effect
+    m.train()
+    m(x[:, :3], x[:, 3:])
+    c3m = next(mod for mod in m.modules() if type(mod).__name__ == 'C3')
+    assert back_to_back(c3m.cv1.conv.weight.data, c3m.cv2.conv.weight.data)   # first training forward packs
