@@ -39,6 +39,22 @@ const char* mmi_last_error(void);
  * that the region is all zero between launches (mmidet_hip/ops.py::check_counters). */
 size_t mmi_workspace_header_bytes(int kind);
 
+/* ---- pre-split operands ("T8") for the three-term bf16 GEMM modes (mmi_set_gemm_precision 2 / 3) ------------------------------
+ * In those modes every fp32 operand value is the sum of three bf16 terms and a product is 6 / 9 bf16 MFMA products; by default the
+ * kernels split each tile when they stage it -- a weight tile once per row tile of the launch, an activation row once per column
+ * tile and tap.  A T8 image holds the terms of a tensor, split ONCE by its producer: per 8 consecutive channels of a row 48 bytes =
+ * [term 0: 8 bf16 | term 1 | term 2], same element indexing as the tensor (element (row, c) with row stride ld lives in the group at
+ * byte (row * ld + (c & ~7)) * 6; channel counts, slice offsets and row strides multiples of 8, 16-byte aligned).  The terms are the
+ * ones the kernels' own split produces, so a GEMM on images is bit-identical to the same GEMM on the fp32 tensors.
+ * mmi_split_t8: the stand-alone converter (src row stride ld, image row stride ld8, both in elements).
+ * mmi_gemm_operands_t8: announces images for the NEXT GEMM launch issued by the calling thread (mmi_conv_fwd / _bn_fwd / _dgrad /
+ * mmi_linear_* without epilogue / the twin forms / mmi_conv_wgrad*), which takes and clears them whatever path it then runs:
+ *   forward: a = image of x, b = image of w;  dgrad: a = image of dy, b = image of w;  wgrad: a = image of dy, b = image of x;
+ *   *_twin: the second problem of a twin launch.  NULL = that operand is split in the kernel (forward / dgrad: weights alone may be
+ *   pre-split; wgrad needs both).  Ignored in the other precision modes and by shapes that take the general loaders. */
+int mmi_split_t8(const float* src, int ld, void* dst, int ld8, int64_t rows, int C, void* stream);
+int mmi_gemm_operands_t8(const void* a_t8, const void* b_t8, const void* a_t8_twin, const void* b_t8_twin);
+
 /* ---- conv / linear as fp32-MFMA implicit GEMM -------------------------------------------------------------------
  * Replaces nn.Conv2d forward/backward at models/common.py:114 (Conv), 764,772 (CEM convs), 333,337 (FFM 1x1),
  * models/yolo_test.py:44 (Detect) and nn.Linear at models/common.py:1167-1170,1254,1257 (a Linear is the 1x1 case

@@ -191,6 +191,19 @@ extern "C" int mmi_set_wgrad_override(int bm, int bn, int splits) {
   return MMI_OK;
 }
 
+namespace mmi_ig {
+const void** t8_pending() {
+  static thread_local const void* pend[4] = {nullptr, nullptr, nullptr, nullptr};
+  return pend;
+}
+}  // namespace mmi_ig
+
+extern "C" int mmi_gemm_operands_t8(const void* a_t8, const void* b_t8, const void* a_t8_twin, const void* b_t8_twin) {
+  const void** pend = t8_pending();
+  pend[0] = a_t8; pend[1] = b_t8; pend[2] = a_t8_twin; pend[3] = b_t8_twin;
+  return MMI_OK;
+}
+
 extern "C" size_t mmi_workspace_header_bytes(int kind) {
   switch (kind) {
     case 0: return WS_HEADER_BYTES;                               // forward / dgrad (one problem)

@@ -60,6 +60,9 @@ struct IgemmP {
   int bn_nnbt;
   float bn_eps, bn_momentum;
   double bn_inv_rows, bn_unbias;  // 1 / rows, rows / (rows - 1)
+  // pre-split operands (igemm_kernel<..., T8>, t8.hip): the T8 images of A and / or B (same element indexing, 6 bytes per element)
+  const void* A8;
+  const void* B8;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -83,6 +86,9 @@ struct WgradP {
   // TAB loaders: the per-pixel {source offset, invalid-tap mask} table of the layer's geometry, precomputed once
   // (mmi_conv_wgrad_table_build: it depends on shapes and strides only, not on data); null = built in the kernel, slab by slab
   const uint2* tab;
+  // pre-split operands (wgrad_kernel<..., T8>): the T8 images of dy and x
+  const void* DY8;
+  const void* X8;
 };
 
 // Twin launches (two problems of one shape in one grid, blockIdx.z = problem): the kernels take ONE parameter block by value, as
@@ -91,10 +97,10 @@ struct WgradP {
 // reference looked the same in the source but cost 2-4x the VALU instructions in the K loops -- the compiler no longer kept
 // the loaders' address parts scalar -- and with them 10-20 % of the dgrad / wgrad kernels' speed: profiles/r03_twin_param_select.txt.)
 struct IgemmDelta {
-  int64_t A, B, C, stat_part, sk_slots, sk_count, aux, aux_out, fold_part, fold_l1, fold_cnt, bn_mi, bn_rmean, bn_rvar, bn_nbt;
+  int64_t A, B, C, stat_part, sk_slots, sk_count, aux, aux_out, fold_part, fold_l1, fold_cnt, bn_mi, bn_rmean, bn_rvar, bn_nbt, A8, B8;
 };
 struct WgradDelta {
-  int64_t DY, X, OUT, OUTB, cnt, DW, DB;
+  int64_t DY, X, OUT, OUTB, cnt, DW, DB, DY8, X8;
 };
 template <typename T>
 __device__ __forceinline__ T* shift_ptr(T* p, int64_t bytes) {
@@ -148,5 +154,10 @@ template <bool DGRAD, bool EPI>
 int launch_igemm_bf16(IgemmP p, const FwdPlan& f, hipStream_t s, const char* who);
 template <bool DGRAD>
 int sk_occupancy(int bn);
+// the pre-split-operand variants (igemm_kernel<..., T8>), instantiated in igemm_fwd_t8.hip / igemm_dgrad_t8.hip
+template <bool DGRAD>
+int launch_igemm_t8(const IgemmP& p, const IgemmDelta& q, const FwdPlan& f, dim3 grid, int t8, hipStream_t s);
+// T8 images announced for the next GEMM launch of this thread (mmi_gemm_operands_t8): [0] = A, [1] = B, [2], [3] = the twin problem's
+const void** t8_pending();
 
 }  // namespace mmi_ig

@@ -197,7 +197,14 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // W41 (narrow outputs: Focus' input gradient has N = 12): the four waves are stacked along M, each owning 32 rows x the whole
 // tile width, and skip the 32-column blocks beyond the last output column -- in the 2 x 2 layout half of the waves would own
 // nothing but padding and leave their SIMDs' matrix pipes idle.
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false>
+// T8 (pre-split operands, PREC = 2 / 3 with the uniform-tap loaders): bit 0 = the weight operand B, bit 1 = the activation operand A
+// arrive as their three bf16 terms, split ONCE by whoever produced them (t8.hip: the optimizer for the weights, the BatchNorm
+// passes for activations and their gradients) instead of by every workgroup that stages a tile of them -- a weight tile is
+// staged by every row tile of the launch, an activation row by every column tile and tap.  Format "T8": per 8 consecutive
+// channels 48 bytes = [term 0: 8 bf16 | term 1 | term 2] (6 bytes per element, rows keep their element stride).  A loader thread
+// fetches one such group (three 16-byte loads) and stores each term to its plane of the LDS row record: no v_cvt, no subtract;
+// the MFMA side does not change, and the terms are the same bits the in-kernel split produces, so results are bit-identical.
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false, int T8 = 0>
 __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p, IgemmDelta dz) {
   // twin launches (two problems of one shape, e.g. the RGB and IR backbone layers of the two-stream model): blockIdx.z picks the
   // problem; problem 1 moves its copy of the operand pointers (igemm_defs.h::IgemmDelta), nothing per lane
@@ -210,7 +217,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
     p.bn_fold.cnt = shift_ptr(p.bn_fold.cnt, dz.fold_cnt);
     p.bn_mi = shift_ptr(p.bn_mi, dz.bn_mi); p.bn_rmean = shift_ptr(p.bn_rmean, dz.bn_rmean); p.bn_rvar = shift_ptr(p.bn_rvar, dz.bn_rvar);
     p.bn_nbt = shift_ptr(p.bn_nbt, dz.bn_nbt);
+    p.A8 = shift_ptr(p.A8, dz.A8); p.B8 = shift_ptr(p.B8, dz.B8);
   }
+  static_assert(T8 == 0 || (UNI && (PREC == 2 || PREC == 3) && BK == 32), "pre-split operands: three-term modes, uniform-tap loaders");
+  constexpr bool A8 = (T8 & 2) != 0, B8 = (T8 & 1) != 0;
   static_assert(!W41 || (DGRAD && !SK && PREC == 0 && !EPI && BM == 128), "the stacked wave layout exists for the plain fp32 dgrad tiles");
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!UNI || VEC, "uniform-tap loaders are a form of the vector loaders");
@@ -228,15 +238,19 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   // the ds_read_b128 of 8 consecutive rows hit 8 different 16-byte bank groups)
   constexpr int RSF = ONE ? 20 : (PREC >= 2 ? 52 : LDS_PAD);
   constexpr int WM = W41 ? BM / 4 : BM / 2, WN = W41 ? BN : BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int RA = BM / RPP;                      // A rows per loader thread
+  // loader geometry per operand: fp32 = 8 threads per tile row with 4 k each (KT, RPP); pre-split = 4 threads with one 8-k group each
+  constexpr int KTA = A8 ? BK / 8 : KT, RPPA = 256 / KTA, KEA = A8 ? 8 : 4;
+  constexpr int KTB = B8 ? BK / 8 : KT, RPPB = 256 / KTB, KEB = B8 ? 8 : 4;
+  constexpr int ESA = A8 ? 6 : (BF ? 2 : 4), ESB = B8 ? 6 : 4;   // bytes per element (byte offsets against the buffer resources)
+  constexpr int RA = BM / RPPA;                     // A rows per loader thread
   constexpr int A_ELEMS = BM * RSF;
   // split-bf16 dgrad: the weight tile stays k-major ([k][n], as it comes from OHWI memory) in two bf16 planes whose rows are
   // padded by 64 B (conflict-free ds_read_b64_tr_b16: the MFMA B operand is fetched with the hardware transpose read)
   constexpr int B_RSB = BN * 2 + 64;                                  // bytes per k row of one plane
   constexpr int B_ELEMS = DGRAD ? (PREC >= 1 ? NP * BK * B_RSB / 4 : BK * BN) : BN * RSF;
   constexpr int STAGE = A_ELEMS + B_ELEMS;
-  constexpr int RB = BN / RPP;                      // fwd: B rows per loader thread
-  constexpr int VPR = BN / 4, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry
+  constexpr int RB = BN / RPPB;                     // fwd: B rows per loader thread
+  constexpr int VPR = BN / KEB, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry (KEB columns per thread)
   __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
   __shared__ int sk_last;
@@ -259,14 +273,15 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   const bool par = !SK && DGRAD && p.par;
   const int nk = (tp.Ktot + BK - 1) / BK;
   const int ntaps = tp.Ktot / p.Kc;
-  const int kq = (t % KT) * 4;  // this thread's k offset inside a slab ([row][k] tiles)
-  const int lrow = t / KT;      // 0..RPP-1
+  const int kq = (t % KTA) * KEA;  // this thread's k offset inside a slab ([row][k] tiles), A operand
+  const int lrow = t / KTA;        // 0..RPPA-1
+  const int kqb = (t % KTB) * KEB, lrowb = t / KTB;   // the same for the forward B operand
   const int l31 = lane & 31, lh = lane >> 5;
   __amdgpu_buffer_rsrc_t srd_a, srd_b;
   if constexpr (UNI) {
     const int64_t margin = ((int64_t)p.KH * p.Ws + p.KW) * p.lda;  // elements in front of A that row offsets may reach into
-    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) - margin * ES), 0, (int)p.a_bytes, 0x00020000);
-    srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+    srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(A8 ? p.A8 : (const void*)p.A) - margin * ESA), 0, (int)p.a_bytes, 0x00020000);
+    srd_b = __builtin_amdgcn_make_buffer_rsrc(B8 ? (void*)p.B8 : (void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   }
 
   // iteration range of this workgroup: data-parallel = the nk slabs of one tile; stream-K = an even share of everything
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
     RowInfo rows[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + lrow + RPP * i;
+      const int m = m0 + lrow + RPPA * i;
       int orow = -1;
       if (lin1) {
         rows[i].base = m < Mc ? 0 : -1;
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         rows[i].base = -1;
         rows[i].ph = rows[i].qw = 0;
       }
-      if (par && (t % KT) == 0) rowmap[lrow + RPP * i] = orow;  // visible after the K loop's barriers
+      if (par && (t % KTA) == 0) rowmap[lrow + RPPA * i] = orow;  // visible after the K loop's barriers
     }
 
     f32x16 acc[TM][TN];
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
     bf16x4 rab[BF ? RA : 1];  // bf16 storage: the A operand arrives as 4 bf16 per load
     constexpr int NB = DGRAD ? KB_IT : RB;
     f32x4 rb[NB];
+    bf16x8 ra8[A8 ? RA : 1][3], rb8[B8 ? NB : 1][3];   // pre-split operands: one 8-k group = three terms of 8 bf16
 
     // ---- UNI: per-thread address parts and tap-validity bits of this tile (see the kernel's header comment) ----
     // Source position of row r under tap (ti, tj):  ih = ihb[r] + sgn * dh * ti,  iw = iwb[r] + sgn * dw * tj  with
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         amask[i] = 0xFFFFFFFFu;
         if (lin1) {
           if (rows[i].base >= 0) {
-            aoff[i] = (uint32_t)((((int64_t)(m0 + lrow + RPP * i) + p.Ws + 1) * p.lda + kq) * ES);  // margin = KH*Ws + KW pixels
+            aoff[i] = (uint32_t)((((int64_t)(m0 + lrow + RPPA * i) + p.Ws + 1) * p.lda + kq) * ESA);  // margin = KH*Ws + KW pixels
             amask[i] = 0u;
           }
         } else if (rows[i].base >= 0) {
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           const int iwb = DGRAD ? ((rows[i].qw - tp.kw0) >> u_sh) : rows[i].qw + tp.kw0;
           const int ihlo = DGRAD ? ihb - u_dh * (u_nth - 1) : ihb, iwlo = DGRAD ? iwb - u_dw * (tp.ntw - 1) : iwb;
           const int64_t pix = rows[i].base + (int64_t)(ihlo + p.KH) * p.Ws + iwlo + p.KW;
-          aoff[i] = (uint32_t)((pix * p.lda + kq) * ES);
+          aoff[i] = (uint32_t)((pix * p.lda + kq) * ESA);
           // separable: a tap is out if its row is out or its column is out
           uint32_t bw = 0, bad = 0;
           for (int tj = 0; tj < tp.ntw; ++tj)
@@ -377,11 +393,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         if (!DGRAD) {
-          const int n = n0 + lrow + RPP * i;
-          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)n * p.ldb + kq) * 4) : OOB;
+          const int n = n0 + lrowb + RPPB * i;
+          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)n * p.ldb + kqb) * ESB) : OOB;
         } else {
-          const int n = n0 + (t % VPR) * 4;
-          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)(t / VPR + RPI * i) * p.ldb + n) * 4) : OOB;
+          const int n = n0 + (t % VPR) * KEB;
+          boff[i] = n < p.Ncol ? (uint32_t)(((int64_t)(t / VPR + RPI * i) * p.ldb + n) * ESB) : OOB;
         }
       }
     }
@@ -414,9 +430,13 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
       if constexpr (UNI) {
         const int tap = u_ti * tp.ntw + u_tj;
         const int dpix = DGRAD ? (u_nth - 1 - u_ti) * u_dh * p.Ws + (tp.ntw - 1 - u_tj) * u_dw : u_ti * u_dh * p.Ws + u_tj * u_dw;
-        const uint32_t soff = (uint32_t)(dpix * p.lda + u_c0) * (uint32_t)ES;
+        const uint32_t soff = (uint32_t)(dpix * p.lda + u_c0) * (uint32_t)ESA;
         const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe(amask[i], tap, 1);   // -1 where this tap leaves the image
-        if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, aoff[i] | (inv & OOB), soff, 0));
+        if constexpr (A8) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            ra8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_a, (aoff[i] | (inv & OOB)) + 16u * pl, soff, 0));
+        } else if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, aoff[i] | (inv & OOB), soff, 0));
         else ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
         return;
       }
@@ -436,6 +456,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         }
         if constexpr (UNI) {
           const int tapw = (tp.kh0 + tp.khs * u_ti) * p.KW + tp.kw0 + tp.kws * u_tj;   // (forward: all taps, so tapw = tap)
+          if constexpr (B8) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(tapw * p.Kc + u_c0) * (uint32_t)ESB, 0));
+          } else
           rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(tapw * p.Kc + u_c0) * 4u, 0));
           return;
         }
@@ -449,6 +474,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         }
         if constexpr (UNI) {
           const int tapw = (tp.kh0 + tp.khs * u_ti) * p.KW + tp.kw0 + tp.kws * u_tj;
+          if constexpr (B8) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * (uint32_t)ESB, 0));
+          } else
           rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * 4u, 0));
           return;
         }
@@ -495,31 +525,46 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         // row record: NP planes of 32 bf16 (64 B each) | 16 B pad
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          bf16x4 tm[NP];
-          if constexpr (BF) tm[0] = rab[i];
-          else split_bf16<NP>(ra[i], tm);
-          __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPP * i) * RSF);
+          __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPPA * i) * RSF);
+          if constexpr (A8) {
 #pragma unroll
-          for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kq) = ra8[i][k];
+          } else {
+            bf16x4 tm[NP];
+            if constexpr (BF) tm[0] = rab[i];
+            else split_bf16<NP>(ra[i], tm);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
+          }
         }
         if constexpr (!DGRAD) {
 #pragma unroll
           for (int i = 0; i < RB; ++i) {
-            bf16x4 tm[NP];
-            split_bf16<NP>(rb[i], tm);
-            __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrow + RPP * i) * RSF);
+            __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrowb + RPPB * i) * RSF);
+            if constexpr (B8) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kqb) = rb8[i][k];
+            } else {
+              bf16x4 tm[NP];
+              split_bf16<NP>(rb[i], tm);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kqb) = tm[k];
+            }
           }
         } else {
           char* base = reinterpret_cast<char*>(Bs);
 #pragma unroll
           for (int i = 0; i < KB_IT; ++i) {
-            bf16x4 tm[NP];
-            split_bf16<NP>(rb[i], tm);
-            char* dst = base + (t / VPR + RPI * i) * B_RSB + (t % VPR) * 8;
+            char* dst = base + (t / VPR + RPI * i) * B_RSB + (t % VPR) * (KEB * 2);
+            if constexpr (B8) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(dst + k * BK * B_RSB) = rb8[i][k];
+            } else {
+              bf16x4 tm[NP];
+              split_bf16<NP>(rb[i], tm);
+#pragma unroll
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
+            }
           }
         }
         return;

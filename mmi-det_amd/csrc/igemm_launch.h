@@ -35,9 +35,22 @@ int sk_occupancy(int bn) {
 
 template <bool DGRAD, bool EPI>
 int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, size_t workspace_bytes, hipStream_t s,
-                 size_t slot_offset, const IgemmP* twin) {
+                 size_t slot_offset, const IgemmP* twin0) {
   const char* who = DGRAD ? "mmi_conv_dgrad" : "mmi_conv_fwd";
   IgemmP p = p0;
+  // T8 images announced for this launch (mmi_gemm_operands_t8): taken and cleared, whatever path the launch then takes
+  IgemmP twin_copy;
+  const IgemmP* twin = twin0;
+  {
+    const void** pend = t8_pending();
+    p.A8 = pend[0]; p.B8 = pend[1];
+    if (twin0 != nullptr) {
+      twin_copy = *twin0;
+      twin_copy.A8 = pend[2]; twin_copy.B8 = pend[3];
+      twin = &twin_copy;
+    }
+    pend[0] = pend[1] = pend[2] = pend[3] = nullptr;
+  }
   p.zero = zero_src();
   if (p.zero == nullptr) {
     mmi_set_error("igemm: cannot resolve the zero-source symbol");
@@ -63,6 +76,24 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       p.c_bytes = c_bytes < (1LL << 31) ? (uint32_t)c_bytes : 0u;
     }
   }
+  // pre-split operands (T8 images handed over with mmi_gemm_operands_t8): bit 0 = weights, bit 1 = activations as well.  The byte
+  // extents of the buffer resources grow by 6 / 4; a shape whose extents no longer fit 31 bits keeps the in-kernel split.
+  int t8 = 0;
+  if (uni && !EPI && (g_gemm_prec == 2 || g_gemm_prec == 3) && p.B8 != nullptr && p.ldb % 8 == 0 && (!DGRAD || p.Ncol % 8 == 0) &&
+      ((uintptr_t)p.B8 & 15) == 0 && (twin == nullptr || twin->B8 != nullptr)) {
+    const int64_t b8 = (int64_t)p.b_bytes / 4 * 6;
+    if (b8 < (1LL << 31)) {
+      t8 = 1;
+      if (p.A8 != nullptr && p.lda % 8 == 0 && ((uintptr_t)p.A8 & 15) == 0 && (twin == nullptr || twin->A8 != nullptr)) {
+        const int64_t a8 = (int64_t)p.a_bytes / 4 * 6;
+        if (a8 < (1LL << 31)) {
+          t8 = 3;
+          p.a_bytes = (uint32_t)a8;
+        }
+      }
+      p.b_bytes = (uint32_t)b8;
+    }
+  }
   // twin launch: a second problem of the same shape (other operand pointers, its own workspace) on gridDim.z = 2
   const int nz = twin != nullptr ? 2 : 1;
   IgemmDelta q{};   // byte distances to the twin problem's operands (everything else is shared: same shape, same schedule)
@@ -83,6 +114,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     q.bn_mi = ptr_delta(t.bn_mi, p.bn_mi); q.bn_rmean = ptr_delta(t.bn_rmean, p.bn_rmean); q.bn_rvar = ptr_delta(t.bn_rvar, p.bn_rvar);
     q.bn_nbt = ptr_delta(t.bn_nbt, p.bn_nbt);
     q.sk_slots = ptr_delta(t.sk_slots, p.sk_slots); q.sk_count = ptr_delta(t.sk_count, p.sk_count);
+    q.A8 = ptr_delta(t.A8, p.A8); q.B8 = ptr_delta(t.B8, p.B8);
   }
   if (f.sk_grid > 0) {
     if (twin != nullptr) {   // (the caller laid out both problems' counters and slots: igemm.hip, "twin launches")
@@ -100,6 +132,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       p.sk_slots = (float*)((char*)workspace + slot_offset);
     }
     const dim3 grid(f.sk_grid, 1, nz), block(256);
+    if (t8) return launch_igemm_t8<DGRAD>(p, q, f, grid, t8, s);
     if (g_gemm_prec == 1) {
       if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p, q);
       else hipLaunchKernelGGL((igemm_kernel<128, 64, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p, q);
@@ -133,6 +166,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     return MMI_OK;
   }
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1, nz), block(256);
+  if (t8) return launch_igemm_t8<DGRAD>(p, q, f, grid, t8, s);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p, q)
   if (vec && (g_gemm_prec == 2 || g_gemm_prec == 3) && uni) {

@@ -32,23 +32,29 @@ namespace {
 // split's end)}; a loader thread adds its own constant tap/channel displacement, tests its own tap bit (2 VALU) and issues
 // a buffer load whose masked lanes return zero.  The dy rows need nothing per slab: constant lane offsets against a buffer
 // resource that is re-based (scalar arithmetic) to the slab's first pixel and ends at the split's last one.
-template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false>
+// T8: dy and x arrive pre-split (t8.h: three bf16 terms per value, 48 bytes per 8 channels, written by the BatchNorm passes that
+// produced them): a loader thread fetches one 8-channel group of a pixel (three 16-byte loads) and stores each term to its plane --
+// the K loop carries no v_cvt / subtract; same terms, same products, bit-identical to the in-kernel split.  No bias gradient.
+template <int BM, int BN, bool VEC, int PREC = 0, bool TAB = false, bool T8 = false>
 __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK == 32 && (PREC < 2 || PREC >= 4)) ? 3 : 2)) void wgrad_kernel(WgradP p, WgradDelta dz) {
   if (blockIdx.z != 0) {  // twin launches: blockIdx.z = problem (see igemm_kernel); uniform
     p.DY = shift_ptr(p.DY, dz.DY); p.X = shift_ptr(p.X, dz.X); p.OUT = shift_ptr(p.OUT, dz.OUT); p.OUTB = shift_ptr(p.OUTB, dz.OUTB);
     p.cnt = shift_ptr(p.cnt, dz.cnt); p.DW = shift_ptr(p.DW, dz.DW); p.DB = shift_ptr(p.DB, dz.DB);
+    p.DY8 = shift_ptr(p.DY8, dz.DY8); p.X8 = shift_ptr(p.X8, dz.X8);
   }
+  static_assert(!T8 || (TAB && (PREC == 2 || PREC == 3)), "pre-split operands: three-term modes, pixel-table loaders");
   static_assert(PREC == 0 || (VEC && BK == 32), "the split-bf16 forms exist for the vector loaders only");
   static_assert(!TAB || (VEC && BK == 32), "pixel-table loaders are a form of the vector loaders");
   constexpr bool BF = PREC == 4;   // bf16 storage: dy and x are bf16 in HBM, dw stays fp32 (see igemm_kernel)
-  constexpr int ES = BF ? 2 : 4;   // bytes per element of dy and x (TAB: byte offsets against buffer resources)
+  constexpr int ES = T8 ? 6 : (BF ? 2 : 4);   // bytes per element of dy and x (TAB: byte offsets against buffer resources)
+  constexpr int KE = T8 ? 8 : 4;              // channels per loader thread and row
   constexpr bool ONE = BF || PREC == 5;   // PREC = 5: fp32 operands, one bf16 term each (see igemm_kernel)
   constexpr int NP = PREC == 0 || ONE ? 1 : (PREC == 3 ? 3 : PREC + 1);
   constexpr int OL = ONE ? 0 : (PREC == 3 ? 2 * (NP - 1) : NP - 1);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr bool PAIR = MMI_WGRAD_PAIR && PREC == 0 && !MMI_WGRAD_LDS_B32;   // interleaved sub-tile rows / columns (see above)
-  constexpr int VA = BM / 4, RPA = 256 / VA, ITA = BK / RPA;
-  constexpr int VB = BN / 4, RPB = 256 / VB, ITB = BK / RPB;
+  constexpr int VA = BM / KE, RPA = 256 / VA, ITA = BK / RPA;
+  constexpr int VB = BN / KE, RPB = 256 / VB, ITB = BK / RPB;
   // split-bf16 (PREC = 1): both tiles stay k-major in two bf16 planes with rows padded by 64 B; the MFMA operands (8
   // consecutive pixels of one channel) come out of ds_read_b64_tr_b16
   constexpr int A_RSB = BM * 2 + 64, B_RSB = BN * 2 + 64;
@@ -73,9 +79,9 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   const int kend = min(kbeg + p.chunk, p.Mpix);
 
   // A loader: float4 along co
-  const int am = m0 + (t % VA) * 4, akr = t / VA;
+  const int am = m0 + (t % VA) * KE, akr = t / VA;
   // B loader: float4 along (tap,ci): fixed per thread
-  const int bn = n0 + (t % VB) * 4, bkr = t / VB;
+  const int bn = n0 + (t % VB) * KE, bkr = t / VB;
   int b_kh[4], b_kw[4], b_ci[4];
   bool b_ok[4];
 #pragma unroll
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
 
   f32x4 ra[ITA], rb[ITB];
   bf16x4 rab[BF ? ITA : 1], rbb[BF ? ITB : 1];
+  bf16x8 ra8[T8 ? ITA : 1][3], rb8[T8 ? ITB : 1][3];   // pre-split operands: one 8-channel group = three terms of 8 bf16
   const int howo = p.Ho * p.Wo;
   const bool want_bias = (p.OUTB != nullptr) && (nt == 0);  // uniform: the first N-tile of each (M-tile, split)
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
     b_tapbit = b_kh[0] * p.KW + b_kw[0];
     b_tapoff = b_ok[0] ? (uint32_t)(((b_kh[0] * p.W + b_kw[0]) * p.ldx + b_ci[0]) * ES) : OOB;
     const int64_t margin = ((int64_t)p.KH * p.W + p.KW) * p.ldx;
-    srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.X) - margin * ES), 0, (int)p.x_bytes, 0x00020000);
+    srd_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(T8 ? p.X8 : (const void*)p.X) - margin * ES), 0, (int)p.x_bytes, 0x00020000);
     tpix = kbeg + wave * BK + (lane & (BK - 1));
     timg = tpix / howo;
     const int rem = tpix - timg * howo;
@@ -142,7 +149,10 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
   uint2 tnext = {0u, 0xFFFFFFFFu};
   auto fetch_table = [&](int j) {
     if constexpr (TAB) {
-      if (gtab && !lin1w && wave == (j & 3) && lane < BK) tnext = p.tab[(int64_t)kbeg + (int64_t)j * BK + lane];
+      if (gtab && !lin1w && wave == (j & 3) && lane < BK) {
+        tnext = p.tab[(int64_t)kbeg + (int64_t)j * BK + lane];
+        if constexpr (T8) tnext.x = (tnext.x >> 2) * 6u;   // (the table holds byte offsets of fp32 elements)
+      }
     }
   };
   auto build_table = [&](int j) {
@@ -206,9 +216,12 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       // the resource starts at the slab's first dy row and ends with the split: rows past the end are out of range -> 0
       const int64_t left = (int64_t)(kend - k0cur) * p.ldy * ES;
       const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<const char*>(p.DY) + (int64_t)k0cur * p.ldy * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
+          (void*)(reinterpret_cast<const char*>(T8 ? p.DY8 : (const void*)p.DY) + (int64_t)k0cur * p.ldy * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
           0x00020000);
-      if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, a_voff[i], 0, 0));
+      if constexpr (T8) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ra8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_a, a_voff[i] + 16u * pl, 0, 0));
+      } else if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, a_voff[i], 0, 0));
       else ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, a_voff[i], 0, 0));
       return;
     }
@@ -236,16 +249,23 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       if (lin1w) {
         const int64_t left = (int64_t)(kend - k0cur) * p.ldx * ES;
         const __amdgpu_buffer_rsrc_t srd_xs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<const char*>(p.X) + (int64_t)k0cur * p.ldx * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
+            (void*)(reinterpret_cast<const char*>(T8 ? p.X8 : (const void*)p.X) + (int64_t)k0cur * p.ldx * ES), 0, left > 0 ? (left < 0x7FFFFFFF ? (int)left : 0x7FFFFFFF) : 0,
             0x00020000);
         const uint32_t voff = b_ok[0] ? (uint32_t)(((bkr + RPB * i) * p.ldx + b_ci[0]) * ES) : OOB;
-        if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_xs, voff, 0, 0));
+        if constexpr (T8) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_xs, voff + 16u * pl, 0, 0));
+        } else if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_xs, voff, 0, 0));
         else rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_xs, voff, 0, 0));
         return;
       }
       const uint2 e = ptab[tab_sel][bkr + RPB * i];
       const uint32_t inv = (uint32_t)__builtin_amdgcn_sbfe((int)e.y, b_tapbit, 1);  // -1: this thread's tap leaves the image
-      if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
+      if constexpr (T8) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, ((e.x + b_tapoff) | (inv & OOB)) + 16u * pl, 0, 0));
+      } else if constexpr (BF) rbb[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
       else rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, (e.x + b_tapoff) | (inv & OOB), 0, 0));
       return;
     }
@@ -288,10 +308,15 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       char* bb = reinterpret_cast<char*>(Bs);
 #pragma unroll
       for (int i = 0; i < ITA; ++i) {
+        char* dst = ab + (akr + RPA * i) * A_RSB + (t % VA) * (KE * 2);
+        if constexpr (T8) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(dst + k * BK * A_RSB) = ra8[i][k];
+          continue;
+        }
         bf16x4 tm[NP];
         if constexpr (BF) tm[0] = rab[i];
         else split_bf16<NP>(ra[i], tm);
-        char* dst = ab + (akr + RPA * i) * A_RSB + (t % VA) * 8;
 #pragma unroll
         for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * A_RSB) = tm[k];
         if (want_bias) {
@@ -305,10 +330,15 @@ __global__ __launch_bounds__(256, (BK == 32 && PREC == 0) ? MMI_WGRAD_OCC : ((BK
       }
 #pragma unroll
       for (int i = 0; i < ITB; ++i) {
+        char* dst = bb + (bkr + RPB * i) * B_RSB + (t % VB) * (KE * 2);
+        if constexpr (T8) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(dst + k * BK * B_RSB) = rb8[i][k];
+          continue;
+        }
         bf16x4 tm[NP];
         if constexpr (BF) tm[0] = rbb[i];
         else split_bf16<NP>(rb[i], tm);
-        char* dst = bb + (bkr + RPB * i) * B_RSB + (t % VB) * 8;
 #pragma unroll
         for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
       }
@@ -885,6 +915,20 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
       x_bytes_u = (uint32_t)x_bytes;
     }
   }
+  // pre-split operands announced for this launch (mmi_gemm_operands_t8: dy image, x image, and the twin problem's): taken and cleared
+  const void* t8p[4];
+  {
+    const void** pend = t8_pending();
+    for (int i = 0; i < 4; ++i) t8p[i] = pend[i], pend[i] = nullptr;
+  }
+  bool t8 = tab && !bf16_io && (g_gemm_prec == 2 || g_gemm_prec == 3) && !want_bias && t8p[0] != nullptr && t8p[1] != nullptr &&
+            (nprob == 1 || (t8p[2] != nullptr && t8p[3] != nullptr)) && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0;
+  if (t8) {
+    const int64_t x8 = (int64_t)x_bytes_u / 4 * 6;
+    for (int i = 0; i < 2 * nprob; ++i) t8 = t8 && ((uintptr_t)t8p[i] & 15) == 0;
+    if (x8 < (1LL << 31) && t8) x_bytes_u = (uint32_t)x8;
+    else t8 = false;
+  }
   WgradP pp[2];
   float* slabs_of[2] = {nullptr, nullptr};
   for (int q = 0; q < nprob; ++q) {
@@ -913,6 +957,7 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
       p.x_bytes = x_bytes_u;
       p.tab = bf16_io ? nullptr : (const uint2*)table;   // (null: the kernel builds its table slab by slab; the precomputed tables hold 4-byte offsets)
     }
+    if (t8) p.DY8 = t8p[2 * q], p.X8 = t8p[2 * q + 1];
   }
   const WgradP& p = pp[0];
   WgradDelta q{};
@@ -920,12 +965,24 @@ int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float
     const WgradP& t = pp[1];
     q.DY = ptr_delta(t.DY, p.DY); q.X = ptr_delta(t.X, p.X); q.OUT = ptr_delta(t.OUT, p.OUT); q.OUTB = ptr_delta(t.OUTB, p.OUTB);
     q.cnt = ptr_delta(t.cnt, p.cnt); q.DW = ptr_delta(t.DW, p.DW); q.DB = ptr_delta(t.DB, p.DB);
+    q.DY8 = ptr_delta(t.DY8, p.DY8); q.X8 = ptr_delta(t.X8, p.X8);
   }
   const dim3 grid(g.mtiles * g.ntiles, g.splits, nprob), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCHW(BM_, BN_, VEC_) \
   hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, VEC_>), grid, block, 0, s, p, q)
-  if (bf16_io && tab) {
+  if (t8) {
+#define LAUNCHW8(BM_, BN_)                                                                                        \
+  do {                                                                                                            \
+    if (g_gemm_prec == 2) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 2, true, true>), grid, block, 0, s, p, q); \
+    else hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 3, true, true>), grid, block, 0, s, p, q);                  \
+  } while (0)
+    if (g.bm == 128 && g.bn == 128) LAUNCHW8(128, 128);
+    else if (g.bm == 128) LAUNCHW8(128, 64);
+    else if (g.bn == 128) LAUNCHW8(64, 128);
+    else LAUNCHW8(64, 64);
+#undef LAUNCHW8
+  } else if (bf16_io && tab) {
 #define LAUNCHWBT(BM_, BN_) hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, true, 4, true>), grid, block, 0, s, p, q)
     if (g.bm == 128 && g.bn == 128) LAUNCHWBT(128, 128);
     else if (g.bm == 128) LAUNCHWBT(128, 64);

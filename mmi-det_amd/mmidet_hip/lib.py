@@ -58,6 +58,8 @@ _SIGS = {
     'mmi_version': (c_int, []),
     'mmi_last_error': (c_char_p, []),
     'mmi_workspace_header_bytes': (c_size_t, [c_int]),
+    'mmi_split_t8': (c_int, [P, c_int, P, c_int, c_int64, c_int, P]),
+    'mmi_gemm_operands_t8': (c_int, [P, P, P, P]),
     'mmi_conv_fwd_row_blocks': (c_int, [POINTER(ConvDesc)]),
     'mmi_set_streamk_slots': (c_int, [c_int]),
     'mmi_set_tile_override': (c_int, [c_int, c_int]),

@@ -75,6 +75,17 @@ def check_counters():
     return len(_zeroed)
 
 
+def t8_image(t, stream=None):
+    """The pre-split ("T8") image of an fp32 rows tensor (include/mmidet_hip.h: mmi_split_t8): a bf16 tensor (..., C/8, 3, 8) with
+    the tensor's leading shape, written by the stand-alone converter on the current stream.  Channel count a multiple of 8."""
+    t, ld = rows_of(t)
+    c = t.shape[-1]
+    assert c % 8 == 0 and t.dtype == torch.float32
+    img = alloc.empty((*t.shape[:-1], c // 8, 3, 8), dtype=torch.bfloat16, device=t.device)
+    lib.split_t8(t.data_ptr(), ld, img.data_ptr(), c, _nrows(t), c, _stream() if stream is None else stream)
+    return img
+
+
 def conv_fwd(x, w, bias, y, part, d, s):
     """mmi_conv_fwd on tensors (None -> NULL) with the stream-K workspace the shape asks for."""
     nb = fwd_plan(d)[0]

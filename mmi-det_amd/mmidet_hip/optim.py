@@ -49,6 +49,12 @@ class _Staging:
             self.done[k].record()
 
 
+def _same_layout(a, b):
+    """Same element order in memory: strides agree on every axis longer than 1 (the stride of a length-1 axis is arbitrary -- a
+    (O,I,1,1) weight is the same bytes whether it was cloned or re-seated by ops.pack_pair)."""
+    return all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 class FusedSGDEMA:
     TAIL_PREFIX = 'Enhance.'     # state_dict prefix of the modules whose backward runs last (models/yolo_test.py: self.Enhance)
 
@@ -80,7 +86,7 @@ class FusedSGDEMA:
         for k, v in msd.items():
             if k in esd and v.dtype.is_floating_point:
                 e = esd[k]
-                assert e.shape == v.shape and e.stride() == v.stride(), 'EMA copy must share the parameter layout: ' + k
+                assert e.shape == v.shape and _same_layout(e, v), 'EMA copy must share the parameter layout: ' + k
                 ema_of[v.data_ptr()] = e
         rows, self._sgd_params = [], []
         done = set()
@@ -143,7 +149,7 @@ class FusedSGDEMA:
                 continue
             if gp == 0:
                 raise RuntimeError('parameter without gradient in an optimiser group (all are trained in the reference)')
-            assert p.grad.stride() == p.stride(), 'gradient layout differs from the parameter layout'
+            assert _same_layout(p.grad, p), 'gradient layout differs from the parameter layout'
         rec['g'][:n] = np.array(ptrs, dtype=np.uint64)
         al = ((rec['p'] | rec['g'] | rec['buf'] | rec['ema']) & np.uint64(15)) == 0
         rec['flags'] = (rec['flags'] & ~np.int32(4)) | np.where(al, 4, 0).astype(np.int32)
