@@ -25,9 +25,23 @@ tab = None
 if tb and os.environ.get('MMIDET_WGRAD_TABLE', '1') != '0':
     tab = torch.empty(tb, dtype=torch.uint8, device=d)
     lib.conv_wgrad_table_build(tab.data_ptr(), desc, st)
+# PMC_PREC = 0 / 2 / 3: GEMM arithmetic (mmi_set_gemm_precision); PMC_T8 = 1: pre-split operand images (mmi_gemm_operands_t8)
+prec, t8 = int(os.environ.get('PMC_PREC', '0')), os.environ.get('PMC_T8', '0') == '1'
+if prec:
+    lib.set_gemm_precision(prec)
+    nb = lib.conv_wgrad_workspace(desc)
+    ws = torch.zeros(max(nb // 4, 1), device=d)
+if t8:
+    x8, w8, dy8 = ops.t8_image(x), ops.t8_image(w.reshape(Co, -1)), ops.t8_image(dy)
 for _ in range(3):
+    if t8:
+        lib.gemm_operands_t8(x8.data_ptr(), w8.data_ptr(), None, None)
     ops.conv_fwd(x, w, None, y, part, desc, st)
+    if t8:
+        lib.gemm_operands_t8(dy8.data_ptr(), w8.data_ptr(), None, None)
     ops.conv_dgrad(dy, w, dx, desc, st)
+    if t8:
+        lib.gemm_operands_t8(dy8.data_ptr(), x8.data_ptr(), None, None)
     lib.conv_wgrad_tab(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), nb, tab.data_ptr() if tab is not None else None, desc, st)
 torch.cuda.synchronize()
 print('flop per launch', 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k)

@@ -21,7 +21,7 @@ def main():
     base = sys.argv[1]
     vals = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
-    for i in range(1, 5):
+    for i in range(1, 6):
         try:
             f = open('%s_%d/p_counter_collection.csv' % (base, i))
         except OSError:
