@@ -275,9 +275,26 @@ def cpu_baseline(workload, seconds_budget=25.0):
         if time.time() - t0 > seconds_budget or n >= 5:
             break
     dt = (time.time() - t0) / n
-    return {'value': round(bs / dt, 4), 'unit': 'paired img/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(bs / dt, 4), 'unit': 'paired img/s', 'cores': cores, 'kind': 'port', 'batch': bs,
             'sample': '%d timed steps of the %s graph at B=%d 640x640 (fwd+loss+bwd+SGD, fp32, torch CPU oracle), %.1f s/step'
                       % (n, workload, bs, dt)}
+
+
+def pin_rank_to_cores(local_rank, local_world, world):
+    """-> 'first-last (n cores)' description of the set this rank was pinned to, or None when nothing was changed."""
+    want = os.environ.get('MMIDET_PIN', '1' if world > 1 else '0')
+    if want == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // max(local_world, 1)
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return '%d-%d (%d cores)' % (mine[0], mine[-1], len(mine))
+    except OSError:
+        return None
 
 
 def main():
@@ -337,6 +354,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+    # One core set per rank, taken BEFORE anything touches the GPU (so that the HIP runtime's own threads inherit it): N Python
+    # threads each enqueue ~3000 launches per step, and the unpinned ones migrate across the box and onto each other's cores.
+    # The ranks of this node split the cores this process may use into equal contiguous blocks, rank i gets block i.
+    # MMIDET_PIN=0 leaves the affinity alone; MMIDET_PIN=1 pins a single rank too (to its whole set: a no-op, reported).
+    cpu_set = pin_rank_to_cores(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), world)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (there is no CPU fallback for the product path)'
     # MMIDET_COMM=gloo: REHEARSAL transport (tests/test_bench_contract_gpu.py): every rank on GPU 0, rendezvous and the bucket
     # collectives over gloo (which carries device tensors through the host; RCCL refuses two ranks on one device) -- the whole
@@ -348,10 +370,11 @@ def main():
     dev = torch.device('cuda', local_rank)
     ddp = world > 1 or args.ddp
     # 'torch' (default): torch.distributed / ProcessGroupNCCL = RCCL.  'native': the library's own communicator (mmi_comm_*: RCCL
-    # called directly on the reducer's HIP stream, collectives capturable into the step graph).  Both run the same bucket logic;
-    # interleaved on one box at world size 1 the native transport's step is 3 ms longer (profiles/r02_ab_comm_world1.txt: 125.2 /
-    # 125.9 vs 122.4 / 122.5 ms, also with the collective itself switched off, so it is the process set-up, not the call) and it
-    # has never run at N > 1, so the transport every N > 1 launch takes by default is the measured-faster, mainstream one.
+    # called directly on the reducer's HIP stream, collectives capturable into the step graph, no watchdog thread).  Both run the
+    # same bucket logic and, re-measured interleaved at world size 1 in round 3, the same step time (native 123.2 / 123.3 ms, torch
+    # 123.0 / 123.4 ms: profiles/r03_ab_comm_world1.txt; round 2's "+3 ms" was the reducer's copy path, fixed since).  Neither has
+    # run at N > 1 on this pool (one-GPU boxes); the default stays the transport every other PyTorch job on a node exercises,
+    # MMIDET_COMM=native selects the other one.
     comm_kind = os.environ.get('MMIDET_COMM', 'torch')
     if ddp:
         import torch.distributed as dist
@@ -494,6 +517,19 @@ def main():
         allte = [torch.zeros_like(te) for _ in range(world)]
         dist.all_gather(allte, te)
         enq_ranks = [float(x) for x in allte]
+    # what the driver's SCALE record can check the line against: the ranks that really took part, the RCCL build, the core sets
+    ranks_seen, rccl_version, cpu_sets = world if not ddp else dist.get_world_size(), None, [cpu_set]
+    if ddp:
+        if comm_kind == 'native':
+            from mmidet_hip import lib as _l0
+            ranks_seen = min(ranks_seen, _l0.comm_world())
+        try:
+            rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = None
+        if world > 1:
+            cpu_sets = [None] * world
+            dist.all_gather_object(cpu_sets, cpu_set)
     timer.on = False
     roof_steps = args.steps
     if not args.no_roofline:
@@ -586,6 +622,7 @@ def main():
                        'gradient_transport': (None if not ddp else 'mmi_allreduce_bucket (RCCL called directly on the reducer stream)'
                                               if comm_kind == 'native' else 'gloo, all ranks on GPU 0 (REHEARSAL of the N > 1 code path: not a measurement)'
                                               if comm_kind == 'gloo' else 'torch.distributed ProcessGroupNCCL'),
+                       'ranks_seen': ranks_seen, 'rccl_version': rccl_version, 'cpu_affinity_per_rank': cpu_sets,
                        'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 2),
                        'host_enqueue_ms_per_step_per_rank': [round(v, 2) for v in enq_ranks],
                        'loss': [round(float(v), 5) for v in items.tolist()]},

@@ -62,6 +62,8 @@ def _ws(nbytes, device, s, tag):
 
 def _aligned(ws):
     """256-byte aligned address inside a workspace tensor allocated with 256 spare bytes."""
+    if ws is None:
+        raise ValueError('this shape has no twin-launch form (mmi_conv_*_workspace_n returned 0): Conv.twin_ok must route it to the lane form')
     p = ws.data_ptr()
     return (p + 255) & ~255
 

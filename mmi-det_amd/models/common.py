@@ -65,6 +65,9 @@ class Conv(nn.Module):
 
     def twin_ok(self, other):
         """Can this layer and `other` (the same layer of the other backbone) run as one twin launch (mmidet_hip/twin_ops.py)?"""
+        co, ci, kh, _ = self.conv.weight.shape
+        if kh == 3 and self.conv.stride[0] == 1 and (ci, co) in ((3, 24), (24, 3)):
+            return False           # the CEM-shaped direct convolutions (csrc/cem.hip) have no twin form: the pair takes the lane form
         return (type(other) is type(self) and hasattr(self, 'bn') and hasattr(other, 'bn') and self.conv.weight.shape == other.conv.weight.shape
                 and self.conv.stride == other.conv.stride and self._act_id() == other._act_id() and self.bn.eps == other.bn.eps
                 and self.bn.momentum == other.bn.momentum and self.bn.training == other.bn.training)

@@ -235,6 +235,8 @@ class Model(nn.Module):
                 if ok:
                     self._follower_of[i], self._leader_of[j] = j, i
                     break
+        # last layer that reads a pair's output (either lane): without autograd the twin tensor can go once that layer has run
+        self._twin_last = {lead: max(cons.get(lead, []) + cons.get(fol, []) + [fol]) for lead, fol in self._follower_of.items()}
         # fan-out plan of the twin tensors (see _plan_lanes): a pair's output with exactly two consuming executions whose first
         # can hand its input on (a Conv pair, a fusion transformer's token pooling) is consumed as (output, alias) there
         for lead, fol in self._follower_of.items():
@@ -256,7 +258,7 @@ class Model(nn.Module):
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        if '_lanes' not in state or '_fan_skip' not in state or '_leader_of' not in state or '_cat_plan' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
+        if '_lanes' not in state or '_fan_skip' not in state or '_leader_of' not in state or '_cat_plan' not in state or '_twin_last' not in state:   # an object written by the reference (or an older build): same modules, no launch plan
             self.two_streams = os.environ.get('MMIDET_TWO_STREAMS', '1') != '0'
             self._plan_lanes()
 
@@ -370,8 +372,13 @@ class Model(nn.Module):
                 return v[0].leader
             return None
 
+        twin_last = getattr(self, '_twin_last', {})
         for m in self.model:
             i = m.i
+            if not grad and tw:                                    # inference: a pair's output lives until its last reader has run
+                for L in [L for L in tw if twin_last.get(L, len(self.model)) < i]:
+                    del tw[L]
+                    self._twin_lanes.pop(L, None)
             if twin and i in self._leader_of and self._leader_of[i] in tw:      # ran with its leader
                 prev = Lane(self._leader_of[i], 1)
                 y.append(prev if i in self.save else None)

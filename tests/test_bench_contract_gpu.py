@@ -61,23 +61,28 @@ def test_self_spawned_rank_with_the_native_transport_world1():
     assert j['value'] > 0 and all(v == v for v in j['config']['loss'])
 
 
-@pytest.mark.parametrize('mode', ['eager', 'auto'])
-def test_two_ranks_rehearsal_on_one_gpu(mode):
+@pytest.mark.parametrize('mode,ranks', [('eager', 2), ('auto', 2), ('auto', 4)])
+def test_two_ranks_rehearsal_on_one_gpu(mode, ranks):
     """`python bench.py --gpus 2` end to end on a one-GPU box: the self-spawn launcher, two ranks (both on GPU 0, collectives over
     gloo: MMIDET_COMM=gloo, a rehearsal transport), broadcast of the initial weights, warm-up, the launch-mode probe with its
     cross-rank decision, the barrier-bracketed timed region with the max over ranks, the per-rank host-time gather and rank 0's
-    single JSON line with the whole-job aggregate -- every line of bench.py the driver's N > 1 scaling run executes except RCCL."""
-    env = dict(os.environ, MMIDET_COMM='gloo')
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--workload', 's_add', '--steps', '3', '--warmup', '2',
-                        '--mode', mode, '--no-cpu-baseline', '--no-split-probe'], capture_output=True, text=True, timeout=900, cwd=REPO,
-                       env=env)
+    single JSON line with the whole-job aggregate -- every line of bench.py the driver's N > 1 scaling run executes except RCCL.
+    Four ranks is as far as a one-GPU box goes (at most 6 processes may hold the card, this one included); each rank pins itself
+    to its own block of cores before touching the GPU and the line reports the ranks seen and their core sets."""
+    env = dict(os.environ, MMIDET_COMM='gloo', MMIDET_POISON='0')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(ranks), '--workload', 's_add', '--steps', '3', '--warmup', '2',
+                        '--mode', mode, '--no-cpu-baseline', '--no-split-probe'] + (['--no-roofline'] if ranks > 2 else []),
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, 'rank 0 alone prints the JSON line: %r' % r.stdout[-500:]
     j = json.loads(lines[0])
     c = j['config']
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and c['parallelism'] == 'dp2' and c['global_batch'] == 2 * c['batch_per_gpu']
+    assert j['n_gpus'] == ranks and j['scaling'] == 'weak' and c['parallelism'] == 'dp%d' % ranks and c['global_batch'] == ranks * c['batch_per_gpu']
     assert abs(j['value'] - c['global_batch'] / (j['ms_per_step'] * 1e-3)) / j['value'] < 1e-3      # whole-job aggregate
-    assert len(c['host_enqueue_ms_per_step_per_rank']) == 2 and 'REHEARSAL' in c['gradient_transport']
+    assert len(c['host_enqueue_ms_per_step_per_rank']) == ranks and 'REHEARSAL' in c['gradient_transport']
+    assert c['ranks_seen'] == ranks and len(c['cpu_affinity_per_rank']) == ranks
+    sets = [v for v in c['cpu_affinity_per_rank'] if v is not None]
+    assert len(set(sets)) == len(sets), 'ranks share a core set: %r' % (c['cpu_affinity_per_rank'],)   # (None: fewer cores than ranks)
     assert all(v == v and abs(v) < 1e3 for v in c['loss']), c['loss']
-    assert 'roofline' in j and 'cpu_baseline' not in j
+    assert ('roofline' in j) == (ranks <= 2) and 'cpu_baseline' not in j

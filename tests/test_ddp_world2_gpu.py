@@ -31,7 +31,7 @@ def _build(world, accumulate):
 
 def _batch(cfg, it, rank):
     from test_step_gpu import batch
-    return batch(cfg, 300 + 2 * it + rank)
+    return batch(cfg, 300 + 8 * it + rank)
 
 
 def _worker(rank, world, port, out):
@@ -58,8 +58,10 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_train_step_world2_on_one_gpu_matches_accumulated_single_process():
-    world = 2
+@pytest.mark.parametrize('world', [2, 4])
+def test_train_step_world2_on_one_gpu_matches_accumulated_single_process(world):
+    """world = 4: bucket ordering, hooks and the cross-rank sequencing with more ranks than any pair test sees (a one-GPU box
+    admits at most 6 processes on the card, this one included, so 8 ranks cannot be rehearsed here)."""
     port = 29700 + os.getpid() % 200
     ctx = mp.get_context('spawn')
     with tempfile.TemporaryDirectory() as out:
@@ -70,11 +72,12 @@ def test_train_step_world2_on_one_gpu_matches_accumulated_single_process():
             p.join(600)
             assert p.exitcode == 0, 'rank process failed (exit code %r)' % (p.exitcode,)
         got = [torch.load(os.path.join(out, 'rank%d.pt' % r)) for r in range(world)]
-    for k, v in got[0]['sd'].items():
-        assert torch.equal(v, got[1]['sd'][k]), 'ranks disagree on %s after %d steps' % (k, STEPS)
-    # single process, the two ranks' batches as two accumulated micro-batches per optimizer step
-    m, ts, cfg = _build(1, 2)
-    ref_losses = [[], []]
+    for r in range(1, world):
+        for k, v in got[0]['sd'].items():
+            assert torch.equal(v, got[r]['sd'][k]), 'ranks 0 and %d disagree on %s after %d steps' % (r, k, STEPS)
+    # single process, the ranks' batches as accumulated micro-batches per optimizer step
+    m, ts, cfg = _build(1, world)
+    ref_losses = [[] for _ in range(world)]
     for it in range(STEPS):
         for r in range(world):
             loss, _ = ts.step(*_batch(cfg, it, r))
@@ -83,8 +86,8 @@ def test_train_step_world2_on_one_gpu_matches_accumulated_single_process():
     from test_ops_gpu import close
     for r in range(world):                       # (the DDP ranks report the loss scaled by world_size, train.py:790)
         for a, b in zip(got[r]['losses'], ref_losses[r]):
-            assert abs(a - world * b) <= 1e-5 * abs(a), (r, a, b)
+            assert abs(a - world * b) <= (1e-5 if world == 2 else 1e-4) * abs(a), (r, a, b)   # (four addends: the all-reduce's order is not the accumulation's)
     ref = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     for k, v in got[0]['sd'].items():
         if v.numel():
-            close(v, ref[k], tol=1e-5, what=k)
+            close(v, ref[k], tol=1e-5 if world == 2 else 2e-4, what=k)

@@ -255,23 +255,20 @@ def test_yolov5l_640_train_step_matches_oracle(gemm):
     close(lg, lo, what='loss', tol=1e-4)
     close(ig, io, what='loss items', tol=1e-4)
     close(cg, co, what='Combine_loss', tol=1e-4)
+    # Gradients: every one of the 1029 tensors is gated against the fp64 arbiter (test_yolov5l_640_gradients_against_the_fp64_arbiter:
+    # e_hip <= max(3 e_cpu32, 3e-3) per tensor); here only that every trainable tensor received a finite gradient of the right
+    # magnitude (the 12-tensor 8e-3 / 4e-2 spot check this replaced could not see a 1 % bug in the other ~1000 tensors).
     og = ref['grads']
     checked = 0
-    errs = []
     for n, p in m.named_parameters():
-        if not any(k in n for k in ('model.1.conv', 'model.2.m.0.cv2.conv', 'model.10.m.4.cv2.conv', 'model.17.m.8.cv1.conv',
-                                    'model.23.conv', 'model.25.cv3.conv', 'model.29.trans_blocks.3.mlp.0.weight',
-                                    'model.13.trans_blocks.0.sa.que_proj.weight', 'model.6.conv2.weight', 'Enhance.conv3',
-                                    'model.49.m.1', 'model.38.m.0.cv2.bn')):
-            continue
         r = og.get(n)
         if r is None or float(r.norm()) < 1e-9:
             continue
-        errs.append((rel_err(p.grad, r), n))
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        ratio = float(p.grad.norm()) / float(r.norm())
+        assert 0.9 < ratio < 1.1, (n, ratio)
         checked += 1
-    errs.sort()
-    assert errs[len(errs) // 2][0] < 8e-3 and errs[-1][0] < 4e-2, errs[-4:]
-    assert checked >= 12
+    assert checked >= 1000, checked
 
 
 def test_yolov5l_640_gradients_against_the_fp64_arbiter():
@@ -389,7 +386,7 @@ def test_yolov5l_640_gradients_against_the_fp64_arbiter():
         nrm = float(g64[n].norm())
         e6 = float((p.grad.detach().double().cpu() - g64[n]).norm()) / nrm
         e_cpu = float((g32[n].double() - g64[n]).norm()) / nrm
-        rows6.append((e6 / max(e_cpu, 1e-9), e6))
+        rows6.append((e6 / max(e_cpu, 1e-9), e6, e_cpu, n))
     r6 = sorted(r[0] for r in rows6)
     summary['bf16x6'] = {'tensors': len(rows6), 'ratio_median': r6[len(r6) // 2], 'ratio_p90': r6[int(0.9 * len(r6))], 'ratio_max': r6[-1],
                          'e_median': sorted(r[1] for r in rows6)[len(rows6) // 2], 'e_max': max(r[1] for r in rows6),
@@ -417,6 +414,14 @@ def test_yolov5l_640_gradients_against_the_fp64_arbiter():
         with open(os.path.join(out, 'fp64_arbiter_summary.json'), 'w') as f:
             json.dump(summary, f, indent=1)
     print(json.dumps(summary))
+    # THE gradient gate: every tensor, e_hip <= max(3 e_cpu32, 3e-3) against the fp64 truth -- the HIP gradient is
+    # never worse than three times the CPU's own fp32 evaluation, or within 3e-3 where the CPU happened to be exceptionally exact.
+    # No exceptions are needed at this seed (a discrete event that hits only the HIP run would show here by name).
+    EXCEPTIONS = ()
+    viol = [(n, '%.2e' % eh, '%.2e' % ec) for _, eh, ec, n in rows if eh > max(3 * ec, 3e-3) and n not in EXCEPTIONS]
+    assert not viol, 'fp32 MFMA path: %d tensors beyond max(3 e_cpu, 3e-3): %s' % (len(viol), viol[:6])
+    viol6 = [(n, '%.2e' % eh, '%.2e' % ec) for _, eh, ec, n in rows6 if eh > max(3 * ec, 3e-3) and n not in EXCEPTIONS]
+    assert not viol6, 'bf16x6: %d tensors beyond max(3 e_cpu, 3e-3): %s' % (len(viol6), viol6[:6])
     assert summary['ratio_median'] <= 1.5, summary
     assert summary['ratio_p90'] <= 3.0, summary
     assert summary['bf16x6']['ratio_median'] <= 2.0 and summary['bf16x6']['ratio_p90'] <= 4.0, summary['bf16x6']    # (as the fp32 path, with slack)
