@@ -119,6 +119,11 @@ int mmi_set_gemm_precision(int mode);
  * multiple of 32 and the tensors are below 2 GiB (same arithmetic, same results bit for bit; ~10 instead of ~100 address
  * instructions per K slab), 0 = the general cursor-based loaders everywhere.  Returns the old value. */
 int mmi_set_uniform_loaders(int on);
+/* A/B switch of the forward/dgrad K loop: 1 = deep prefetch (double-buffered LDS tile, global loads two K slabs ahead in two
+ * register sets, one barrier per slab, two workgroups per CU) wherever the uniform-tap loaders apply, 0 = single LDS stage with the
+ * next slab prefetched into registers (three workgroups per CU).  Same arithmetic and summation order: results are bit-identical.
+ * Initial value from MMIDET_PF2 (default: see DESIGN.md).  Returns the old value. */
+int mmi_set_deep_prefetch(int on);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
 int mmi_set_tile_override(int bm, int bn);

@@ -157,6 +157,10 @@ int sk_occupancy(int bn);
 // the pre-split-operand variants (igemm_kernel<..., T8>), instantiated in igemm_fwd_t8.hip / igemm_dgrad_t8.hip
 template <bool DGRAD>
 int launch_igemm_t8(const IgemmP& p, const IgemmDelta& q, const FwdPlan& f, dim3 grid, int t8, hipStream_t s);
+// the deep-prefetch variants (igemm_kernel<..., PF2>), instantiated in igemm_fwd_pf2.hip / igemm_dgrad_pf2.hip
+template <bool DGRAD>
+int launch_igemm_pf2(const IgemmP& p, const IgemmDelta& q, const FwdPlan& f, dim3 grid, int t8, hipStream_t s);
+extern int g_pf2;   // mmi_set_deep_prefetch / MMIDET_PF2: 1 = take the deep-prefetch variants where they exist
 // T8 images announced for the next GEMM launch of this thread (mmi_gemm_operands_t8): [0] = A, [1] = B, [2], [3] = the twin problem's
 const void** t8_pending();
 

@@ -1,5 +1,7 @@
 // The forward / data-gradient implicit-GEMM kernel template and its device helpers (see igemm.hip for the design notes).
 #pragma once
+#include <type_traits>
+
 #include "igemm_defs.h"
 
 namespace mmi_ig {
@@ -204,8 +206,12 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // channels 48 bytes = [term 0: 8 bf16 | term 1 | term 2] (6 bytes per element, rows keep their element stride).  A loader thread
 // fetches one such group (three 16-byte loads) and stores each term to its plane of the LDS row record: no v_cvt, no subtract;
 // the MFMA side does not change, and the terms are the same bits the in-kernel split produces, so results are bit-identical.
-template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false, int T8 = 0>
-__global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p, IgemmDelta dz) {
+// PF2 (deep prefetch): the LDS tile is double-buffered and the global loads run TWO slabs ahead in two register sets -- slab s + 3
+// is requested at the top of iteration s, right after slab s + 1 (requested two iterations earlier) has gone from its registers
+// to the idle LDS buffer -- so a load has two whole MFMA phases to arrive instead of a fraction of one, and an iteration has one
+// barrier instead of two.  Costs a second LDS stage and a second register set: two workgroups per CU.
+template <int BM, int BN, bool DGRAD, bool VEC, bool SK, int PREC = 0, bool EPI = false, bool UNI = false, bool W41 = false, int T8 = 0, bool PF2 = false>
+__global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 2 || PREC >= 4)) ? (UNI ? MMI_UNI_OCC : 3) : 2) void igemm_kernel(IgemmP p, IgemmDelta dz) {
   // twin launches (two problems of one shape, e.g. the RGB and IR backbone layers of the two-stream model): blockIdx.z picks the
   // problem; problem 1 moves its copy of the operand pointers (igemm_defs.h::IgemmDelta), nothing per lane
   if (blockIdx.z != 0) {  // uniform
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
     p.bn_nbt = shift_ptr(p.bn_nbt, dz.bn_nbt);
     p.A8 = shift_ptr(p.A8, dz.A8); p.B8 = shift_ptr(p.B8, dz.B8);
   }
+  static_assert(!PF2 || (VEC && UNI), "deep prefetch: a form of the uniform-tap loaders");
+  constexpr int NSTG = PF2 ? 2 : MMI_IGEMM_STAGES, NS = PF2 ? 2 : 1;   // LDS stages, register sets of staged slabs
   static_assert(T8 == 0 || (UNI && (PREC == 2 || PREC == 3) && BK == 32), "pre-split operands: three-term modes, uniform-tap loaders");
   constexpr bool A8 = (T8 & 2) != 0, B8 = (T8 & 1) != 0;
   static_assert(!W41 || (DGRAD && !SK && PREC == 0 && !EPI && BM == 128), "the stacked wave layout exists for the plain fp32 dgrad tiles");
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   constexpr int RB = BN / RPPB;                     // fwd: B rows per loader thread
   constexpr int VPR = BN / KEB, RPI = 256 / VPR, KB_IT = BK / RPI;  // dgrad B loader geometry (KEB columns per thread)
-  __shared__ __align__(16) float smem[MMI_IGEMM_STAGES * STAGE];
+  __shared__ __align__(16) float smem[NSTG * STAGE];
   __shared__ int rowmap[BM];  // parity mode: tile row -> output pixel
   __shared__ int sk_last;
   __shared__ int bn_flag;
@@ -348,11 +356,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[RA];
-    bf16x4 rab[BF ? RA : 1];  // bf16 storage: the A operand arrives as 4 bf16 per load
+    f32x4 ra[NS][RA];
+    bf16x4 rab[NS][BF ? RA : 1];  // bf16 storage: the A operand arrives as 4 bf16 per load
     constexpr int NB = DGRAD ? KB_IT : RB;
-    f32x4 rb[NB];
-    bf16x8 ra8[A8 ? RA : 1][3], rb8[B8 ? NB : 1][3];   // pre-split operands: one 8-k group = three terms of 8 bf16
+    f32x4 rb[NS][NB];
+    bf16x8 ra8[NS][A8 ? RA : 1][3], rb8[NS][B8 ? NB : 1][3];   // pre-split operands: one 8-k group = three terms of 8 bf16
 
     // ---- UNI: per-thread address parts and tap-validity bits of this tile (see the kernel's header comment) ----
     // Source position of row r under tap (ti, tj):  ih = ihb[r] + sgn * dh * ti,  iw = iwb[r] + sgn * dw * tj  with
@@ -422,9 +430,9 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         for (int i = 0; i < NB; ++i) cb[i].init(k0cur + t / VPR + RPI * i, p.Kc, tp.ntw);
       }
     }
-    auto load_a_row = [&](int i) {
+    auto load_a_row = [&](int i, int rs = 0) {
       if (!VEC) {
-        ra[i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
+        ra[rs][i] = load_a<DGRAD, VEC>(p, tp, rows[i], k0cur + kq);
         return;
       }
       if constexpr (UNI) {
@@ -435,23 +443,23 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         if constexpr (A8) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            ra8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_a, (aoff[i] | (inv & OOB)) + 16u * pl, soff, 0));
-        } else if constexpr (BF) rab[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, aoff[i] | (inv & OOB), soff, 0));
-        else ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
+            ra8[rs][i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_a, (aoff[i] | (inv & OOB)) + 16u * pl, soff, 0));
+        } else if constexpr (BF) rab[rs][i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(srd_a, aoff[i] | (inv & OOB), soff, 0));
+        else ra[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a, aoff[i] | (inv & OOB), soff, 0));
         return;
       }
       int64_t pix = 0;
       const bool ok = (ca.tap < ntaps) & src_pixel<DGRAD>(p, rows[i], tp.kh0 + tp.khs * ca.ti, tp.kw0 + tp.kws * ca.tj, pix);
       if constexpr (BF)
-        rab[i] = *reinterpret_cast<const bf16x4*>(ok ? reinterpret_cast<const char*>(p.A) + (pix * p.lda + ca.c) * 2
-                                                     : reinterpret_cast<const char*>(ZERO_SRC));
+        rab[rs][i] = *reinterpret_cast<const bf16x4*>(ok ? reinterpret_cast<const char*>(p.A) + (pix * p.lda + ca.c) * 2
+                                                         : reinterpret_cast<const char*>(ZERO_SRC));
       else
-        ra[i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
+        ra[rs][i] = *reinterpret_cast<const f32x4*>(ok ? p.A + pix * p.lda + ca.c : ZERO_SRC);
     };
-    auto load_b_row = [&](int i) {
+    auto load_b_row = [&](int i, int rs = 0) {
       if (!DGRAD) {
         if (!VEC) {
-          rb[i] = load_b_nk<VEC>(p, n0 + lrow + RPP * i, k0cur + kq);
+          rb[rs][i] = load_b_nk<VEC>(p, n0 + lrow + RPP * i, k0cur + kq);
           return;
         }
         if constexpr (UNI) {
@@ -459,17 +467,17 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           if constexpr (B8) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-              rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(tapw * p.Kc + u_c0) * (uint32_t)ESB, 0));
+              rb8[rs][i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(tapw * p.Kc + u_c0) * (uint32_t)ESB, 0));
           } else
-          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(tapw * p.Kc + u_c0) * 4u, 0));
+          rb[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(tapw * p.Kc + u_c0) * 4u, 0));
           return;
         }
         const int n = n0 + lrow + RPP * i, k = k0cur + kq;
         const bool ok = (n < p.Ncol) & (k < tp.Ktot);
-        rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
+        rb[rs][i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)n * p.ldb + k : ZERO_SRC);
       } else {
         if (!VEC) {
-          rb[i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
+          rb[rs][i] = load_b_kn<VEC>(p, tp, k0cur + t / VPR + RPI * i, n0 + (t % VPR) * 4);
           return;
         }
         if constexpr (UNI) {
@@ -477,15 +485,15 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           if constexpr (B8) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-              rb8[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * (uint32_t)ESB, 0));
+              rb8[rs][i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i] + 16u * pl, (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * (uint32_t)ESB, 0));
           } else
-          rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * 4u, 0));
+          rb[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_b, boff[i], (uint32_t)(u_c0 * p.ldb + tapw * p.Ncol) * 4u, 0));
           return;
         }
         const int n = n0 + (t % VPR) * 4;
         const bool ok = (cb[i].tap < ntaps) & (n < p.Ncol);
         const int tapw = (tp.kh0 + tp.khs * cb[i].ti) * p.KW + tp.kw0 + tp.kws * cb[i].tj;
-        rb[i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)cb[i].c * p.ldb + (int64_t)tapw * p.Ncol + n : ZERO_SRC);
+        rb[rs][i] = *reinterpret_cast<const f32x4*>(ok ? p.B + (int64_t)cb[i].c * p.ldb + (int64_t)tapw * p.Ncol + n : ZERO_SRC);
       }
     };
     auto advance = [&]() {  // move every cursor to the next slab
@@ -512,13 +520,13 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         }
       }
     };
-    auto gload = [&]() {
+    auto gload = [&](int rs = 0) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) load_a_row(i);
+      for (int i = 0; i < RA; ++i) load_a_row(i, rs);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) load_b_row(i);
+      for (int i = 0; i < NB; ++i) load_b_row(i, rs);
     };
-    auto lstore = [&](int stage) {
+    auto lstore = [&](int stage, int rs = 0) {
       float* As = smem + stage * STAGE;
       float* Bs = As + A_ELEMS;
       if constexpr (PREC >= 1) {
@@ -528,11 +536,11 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           __bf16* row = reinterpret_cast<__bf16*>(As + (lrow + RPPA * i) * RSF);
           if constexpr (A8) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kq) = ra8[i][k];
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kq) = ra8[rs][i][k];
           } else {
             bf16x4 tm[NP];
-            if constexpr (BF) tm[0] = rab[i];
-            else split_bf16<NP>(ra[i], tm);
+            if constexpr (BF) tm[0] = rab[rs][i];
+            else split_bf16<NP>(ra[rs][i], tm);
 #pragma unroll
             for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kq) = tm[k];
           }
@@ -543,10 +551,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
             __bf16* row = reinterpret_cast<__bf16*>(Bs + (lrowb + RPPB * i) * RSF);
             if constexpr (B8) {
 #pragma unroll
-              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kqb) = rb8[i][k];
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(row + 32 * k + kqb) = rb8[rs][i][k];
             } else {
               bf16x4 tm[NP];
-              split_bf16<NP>(rb[i], tm);
+              split_bf16<NP>(rb[rs][i], tm);
 #pragma unroll
               for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(row + 32 * k + kqb) = tm[k];
             }
@@ -558,10 +566,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
             char* dst = base + (t / VPR + RPI * i) * B_RSB + (t % VPR) * (KEB * 2);
             if constexpr (B8) {
 #pragma unroll
-              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(dst + k * BK * B_RSB) = rb8[i][k];
+              for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(dst + k * BK * B_RSB) = rb8[rs][i][k];
             } else {
               bf16x4 tm[NP];
-              split_bf16<NP>(rb[i], tm);
+              split_bf16<NP>(rb[rs][i], tm);
 #pragma unroll
               for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x4*>(dst + k * BK * B_RSB) = tm[k];
             }
@@ -570,26 +578,20 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         return;
       }
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDS_PAD + kq) = ra[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDS_PAD + kq) = ra[rs][i];
       if (!DGRAD) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * LDS_PAD + kq) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * LDS_PAD + kq) = rb[rs][i];
       } else {
 #pragma unroll
-        for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[i];
+        for (int i = 0; i < KB_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (t / VPR + RPI * i) * BN + (t % VPR) * 4) = rb[rs][i];
       }
     };
 
-    gload();
-    lstore(0);
-    __syncthreads();
-
-    for (int ks = ks0; ks < ks1; ++ks) {
-      // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
-      // masked to the zero source, so the last iteration only stages zeros (or, in a stream-K segment that stops short
-      // of the tile's end, an unused slab) into the idle buffer.
-      advance();
-      const float* As = smem + (MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0) * STAGE;
+    // one slab's MFMA phase from LDS stage `stg` (spread: the next slab's global loads go out piecewise between the MFMA groups)
+    auto mfma_phase = [&](int stg, auto spread) {
+      constexpr bool SPREAD = decltype(spread)::value;
+      const float* As = smem + stg * STAGE;
       const float* Bs = As + A_ELEMS;
       if constexpr (PREC >= 1) {
 #pragma unroll
@@ -597,10 +599,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
           // the next slab's global loads: two thirds ahead of the first 16-k block, the rest ahead of the second
 #pragma unroll
           for (int i = 0; i < RA; ++i)
-            if (kb == 0 ? (i % 3 != 2) : (i % 3 == 2)) load_a_row(i);
+            if (SPREAD && (kb == 0 ? (i % 3 != 2) : (i % 3 == 2))) load_a_row(i);
 #pragma unroll
           for (int i = 0; i < NB; ++i)
-            if (kb == 0 ? ((RA + i) % 3 != 2) : ((RA + i) % 3 == 2)) load_b_row(i);
+            if (SPREAD && (kb == 0 ? ((RA + i) % 3 != 2) : ((RA + i) % 3 == 2))) load_b_row(i);
           bf16x8 af[NP][TM], bf[NP][TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
@@ -643,10 +645,10 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
         // 1024 MFMA cycles then cover the tail of the load latency before the LDS stores below)
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-          if (MMI_LOAD_SPREAD(i, g)) load_a_row(i);
+          if (SPREAD && MMI_LOAD_SPREAD(i, g)) load_a_row(i);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-          if (MMI_LOAD_SPREAD(RA + i, g)) load_b_row(i);
+          if (SPREAD && MMI_LOAD_SPREAD(RA + i, g)) load_b_row(i);
         // a wave whose 32-column blocks all lie beyond the last output column (Focus' input gradient: N = 12 in a 64-wide
         // tile) has nothing to multiply: it still loads and synchronises, but leaves the matrix pipe to the others
         if constexpr (DGRAD && BN == 64 && !SK && !W41) {      // (only where it occurs: elsewhere the branch costs registers)
@@ -679,10 +681,48 @@ __global__ __launch_bounds__(256, (MMI_IGEMM_STAGES == 1 && BK == 32 && (PREC < 
             }
       }
       }
+    };
+    if constexpr (PF2) {
+      // slab r (relative to ks0) is computed from LDS stage r & 1; register set (r + 1) & 1 holds slab r + 1 on entry to iteration r
+      gload(0);
+      lstore(0, 0);
+      advance();
+      gload(1);
+      advance();
+      gload(0);
+      __syncthreads();
+      for (int ks = ks0; ks < ks1; ks += 2) {
+        lstore(1, 1);          // slab r + 1 (requested two iterations ago) -> the idle stage
+        advance();
+        gload(1);              // slab r + 3
+        mfma_phase(0, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (ks + 1 < ks1) {
+          lstore(0, 0);
+          advance();
+          gload(0);
+          mfma_phase(1, std::false_type{});
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+        }
+      }
+    } else {
+    gload();
+    lstore(0);
+    __syncthreads();
+
+    for (int ks = ks0; ks < ks1; ++ks) {
+      // The next slab is fetched unconditionally (straight-line code, counted waits): past the end of K every lane is
+      // masked to the zero source, so the last iteration only stages zeros (or, in a stream-K segment that stops short
+      // of the tile's end, an unused slab) into the idle buffer.
+      advance();
+      mfma_phase(MMI_IGEMM_STAGES == 2 ? ((ks - ks0) & 1) : 0, std::true_type{});
       __builtin_amdgcn_sched_barrier(0);  // keep the LDS stores (and their vmcnt waits) behind every MFMA of the slab
       if (MMI_IGEMM_STAGES == 1) __syncthreads();  // single LDS stage: everyone is done reading before it is overwritten
       lstore(MMI_IGEMM_STAGES == 2 ? ((ks - ks0 + 1) & 1) : 0);
       __syncthreads();
+    }
     }
     it += ks1 - ks0;
 

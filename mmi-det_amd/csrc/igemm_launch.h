@@ -132,6 +132,7 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
       p.sk_slots = (float*)((char*)workspace + slot_offset);
     }
     const dim3 grid(f.sk_grid, 1, nz), block(256);
+    if (g_pf2 && uni && !EPI && g_gemm_prec != 1 && (t8 == 0 || t8 == 3)) return launch_igemm_pf2<DGRAD>(p, q, f, grid, t8, s);
     if (t8) return launch_igemm_t8<DGRAD>(p, q, f, grid, t8, s);
     if (g_gemm_prec == 1) {
       if (f.bn == 128) hipLaunchKernelGGL((igemm_kernel<128, 128, DGRAD, true, true, 1, EPI>), grid, block, 0, s, p, q);
@@ -166,6 +167,8 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     return MMI_OK;
   }
   const dim3 grid(f.mtiles * f.ntiles, p.par ? 4 : 1, nz), block(256);
+  if (g_pf2 && uni && !EPI && g_gemm_prec != 1 && (t8 == 0 || t8 == 3) && !(DGRAD && f.bm == 128 && f.bn == 64 && p.Ncol <= 32))
+    return launch_igemm_pf2<DGRAD>(p, q, f, grid, t8, s);
   if (t8) return launch_igemm_t8<DGRAD>(p, q, f, grid, t8, s);
 #define LAUNCH(BM_, BN_, VEC_)                                                                      \
   hipLaunchKernelGGL((igemm_kernel<BM_, BN_, DGRAD, VEC_, false, 0, (VEC_) && EPI>), grid, block, 0, s, p, q)

@@ -117,3 +117,39 @@ def test_announced_images_are_consumed_by_the_next_launch_only():
     finally:
         lib.set_gemm_precision(0)
     assert not torch.equal(y1, y0) and torch.equal(y2, y0)
+
+
+@pytest.mark.parametrize('mode', [0, 3], ids=['fp32', 'bf16x9'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_deep_prefetch_k_loop_is_bit_identical(shape, mode):
+    """mmi_set_deep_prefetch(1): double-buffered LDS tile, global loads two slabs ahead -- the same products summed in the same order."""
+    from mmidet_hip import alloc, lib, ops
+    N, H, W, Cin, Cout, k, s = shape
+    d = dev()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(d)
+    desc = ops._desc((N, H, W, Cin), Cout, k, s, Cin, Cout)
+    dy = torch.randn(N, desc.Ho, desc.Wo, Cout, generator=g).to(d)
+    part = torch.empty((lib.conv_fwd_row_blocks(desc) + 64) * 2 * Cout, device=d)
+
+    def run():
+        y = alloc.empty((N, desc.Ho, desc.Wo, Cout), dtype=torch.float32, device=d)
+        dx = alloc.empty_like(x)
+        ops.conv_fwd(x, w, None, y, part, desc, st)
+        ops.conv_dgrad(dy, w, dx, desc, st)
+        torch.cuda.synchronize()
+        return y, dx, part.clone()
+
+    lib.set_gemm_precision(mode)
+    try:
+        base = run()
+        lib.set_deep_prefetch(1)
+        deep = run()
+    finally:
+        lib.set_deep_prefetch(0)
+        lib.set_gemm_precision(0)
+    for name, a, b in zip(('y', 'dx', 'BN partials'), base, deep):
+        n = a.numel() if name != 'BN partials' else lib.conv_fwd_row_blocks(desc) * 2 * Cout
+        assert torch.equal(a.reshape(-1)[:n], b.reshape(-1)[:n]), name

@@ -18,8 +18,11 @@ SHAPES = [(16, 160, 160, 64, 64, 3, 1), (16, 80, 80, 128, 128, 3, 1), (16, 40, 4
 def main():
     d = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
-    modes = [('fp32', 0, 0), ('x9', 3, 0), ('x9+w8', 3, 1), ('x9+t8', 3, 3), ('x6', 2, 0), ('x6+t8', 2, 3)]
-    print('%-32s %-6s' % ('shape', 'dir') + ''.join('%9s' % m[0] for m in modes) + '   (TFLOP/s fp32-equivalent)')
+    modes = [('fp32', 0, 0, 0), ('fp32/pf2', 0, 0, 1), ('x9', 3, 0, 0), ('x9/pf2', 3, 0, 1), ('x9+t8', 3, 3, 0), ('x9+t8/pf2', 3, 3, 1), ('x6', 2, 0, 0),
+             ('x6/pf2', 2, 0, 1), ('x6+t8', 2, 3, 0), ('x6+t8/pf2', 2, 3, 1)]
+    if os.environ.get('BENCH_MODES'):
+        modes = [m for m in modes if m[0] in os.environ['BENCH_MODES'].split(',')]
+    print('%-32s %-6s' % ('shape', 'dir') + ''.join('%10s' % m[0] for m in modes) + '   (TFLOP/s fp32-equivalent)')
     for (B, H, W, Ci, Co, k, s) in SHAPES:
         x = torch.randn(B, H, W, Ci, device=d)
         w = torch.randn(Co, k, k, Ci, device=d) * 0.05
@@ -35,8 +38,9 @@ def main():
             lib.conv_wgrad_table_build(tab.data_ptr(), desc, st)
         fl = 2.0 * B * desc.Ho * desc.Wo * Co * Ci * k * k
         res = {'fwd': [], 'dgrad': [], 'wgrad': []}
-        for name, prec, t8 in modes:
+        for name, prec, t8, pf2 in modes:
             lib.set_gemm_precision(prec)
+            lib.set_deep_prefetch(pf2)
             nb = lib.conv_wgrad_workspace(desc)
             ws = torch.zeros(max(nb // 4, 1), device=d)
             part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co, device=d)
@@ -60,8 +64,9 @@ def main():
             res['dgrad'].append(fl / timeit(dgrad) / 1e9)
             res['wgrad'].append(fl / timeit(wgrad) / 1e9)
             lib.set_gemm_precision(0)
+            lib.set_deep_prefetch(0)
         for dname, vals in res.items():
-            print('%-32s %-6s' % (str((B, H, W, Ci, Co, k, s)), dname) + ''.join('%9.1f' % v for v in vals), flush=True)
+            print('%-32s %-6s' % (str((B, H, W, Ci, Co, k, s)), dname) + ''.join('%10.1f' % v for v in vals), flush=True)
 
 
 if __name__ == '__main__':
