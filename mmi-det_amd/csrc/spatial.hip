@@ -278,17 +278,21 @@ __global__ __launch_bounds__(256) void separation_loss_kernel(const float* __res
 
 // ---- IGM + CBM statistics: one pass over in_rgb / in_ir, the fused map recomputed on the fly from the 8x8 tokens ----
 // acc[0..7] = sum a, b, f, a^2, b^2, f^2, a f, b f ; acc[8..10] = sum_pixels |normalize(d)|^2 for the 3 pairings
-__global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
-                                                           int ldb, const float* __restrict__ tok, int N, int H, int W, int C,
-                                                           double* __restrict__ acc, unsigned int* __restrict__ hist) {
-  // (an LDS atomic costs its ~64 cycles per wave instruction whether or not the lanes collide -- 16 privatised copies of every
-  //  bin made the kernel slower, 403 -> 493 us -- so what counts is the NUMBER of atomic instructions: full waves, below)
-  __shared__ unsigned int lh[3][256];
+// Histograms: an LDS atomic instruction is served one lane per clock per BANK, so what it costs is its worst bank: with one copy
+// of the 3 x 256 bins every wave instruction piles up on the few banks its lanes' bins fall into (measured: ~64 clocks, the round-3
+// kernel's 275 us), and copies laid out copy-major change nothing (bank = bin % 64 whatever the copy: tried in round 2, slower).
+// Here every bin has HC copies side by side -- word (hist * 256 + bin) * HC + (lane % HC) -- so a lane's bank is its own copy
+// index plus HC * (bin parity bits): lanes of one instruction collide at most 64 / HC-fold (two-fold at HC = 32) whatever the data.
+constexpr int HC = 32;   // 3 x 256 x 32 x 4 B = 96 KB of LDS: one 1024-thread workgroup per CU
+__global__ __launch_bounds__(1024) void fusion_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                            int ldb, const float* __restrict__ tok, int N, int H, int W, int C,
+                                                            double* __restrict__ acc, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int lh[3 * 256 * HC];
   __shared__ double lacc[11];
-  for (int i = threadIdx.x; i < 768; i += 256) (&lh[0][0])[i] = 0u;
+  for (int i = threadIdx.x; i < 3 * 256 * HC; i += 1024) lh[i] = 0u;
   if (threadIdx.x < 11) lacc[threadIdx.x] = 0.0;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, hc = lane & (HC - 1);
   const int64_t npix = (int64_t)N * H * W;
   const int cv = C / 4;
   // A wave covers 64 channel quads: with C < 256 that is several pixels side by side (C = 128 at P2: two), so that every
@@ -298,8 +302,8 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
   float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float cs[3] = {0.f, 0.f, 0.f};
   const int64_t img = (int64_t)H * W;
-  const int64_t wpix = (int64_t)gridDim.x * 4 * ppw;
-  for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw; base < npix; base += wpix) {
+  const int64_t wpix = (int64_t)gridDim.x * 16 * ppw;
+  for (int64_t base = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * ppw; base < npix; base += wpix) {
     const int64_t pix = base + sub;
     const bool live = pix < npix;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -324,9 +328,9 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) {
           const float x = av[k], y = bv[k], f = fv[k];
           m[0] += x; m[1] += y; m[2] += f; m[3] += x * x; m[4] += y * y; m[5] += f * f; m[6] += x * f; m[7] += y * f;
-          if (x >= 0.f && x <= 1.f) atomicAdd(&lh[0][min((int)(x * 256.0f), 255)], 1u);
-          if (y >= 0.f && y <= 1.f) atomicAdd(&lh[1][min((int)(y * 256.0f), 255)], 1u);
-          if (f >= 0.f && f <= 1.f) atomicAdd(&lh[2][min((int)(f * 256.0f), 255)], 1u);
+          if (x >= 0.f && x <= 1.f) atomicAdd(&lh[(0 * 256 + min((int)(x * 256.0f), 255)) * HC + hc], 1u);
+          if (y >= 0.f && y <= 1.f) atomicAdd(&lh[(1 * 256 + min((int)(y * 256.0f), 255)) * HC + hc], 1u);
+          if (f >= 0.f && f <= 1.f) atomicAdd(&lh[(2 * 256 + min((int)(f * 256.0f), 255)) * HC + hc], 1u);
         }
         const f32x4 dp = av - bv;
         d0 += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] + dp[3] * dp[3];
@@ -367,9 +371,11 @@ __global__ __launch_bounds__(256) void fusion_stats_kernel(const float* __restri
   }
   __syncthreads();
   if (threadIdx.x < 11) atomicAdd(&acc[threadIdx.x], lacc[threadIdx.x]);
-  for (int i = threadIdx.x; i < 768; i += 256) {
-    const unsigned int v = (&lh[0][0])[i];
-    if (v) atomicAdd(&hist[i], v);
+  if (threadIdx.x < 768) {                          // fold the HC copies of this thread's bin (rotated start: no bank pile-up)
+    unsigned int v = 0u;
+#pragma unroll 8
+    for (int c = 0; c < HC; ++c) v += lh[threadIdx.x * HC + ((c + threadIdx.x) & (HC - 1))];
+    if (v) atomicAdd(&hist[threadIdx.x], v);
   }
 }
 
@@ -488,9 +494,10 @@ extern "C" int mmi_fusion_stats(const float* in_rgb, int lda, const float* in_ir
   double* acc = (double*)workspace;
   unsigned int* hist = (unsigned int*)(acc + 11);
   const int64_t npix = (int64_t)N * H * W;
-  int blocks = (int)((npix + 3) / 4);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(fusion_stats_kernel, dim3(blocks), dim3(256), 0, s, in_rgb, lda, in_ir, ldb, tokens, N, H, W, C, acc, hist);
+  int blocks = (int)((npix + 15) / 16);
+  const int cus = 256;     // one 1024-thread workgroup per CU (96 KB of LDS histograms each)
+  if (blocks > cus) blocks = cus;
+  hipLaunchKernelGGL(fusion_stats_kernel, dim3(blocks), dim3(1024), 0, s, in_rgb, lda, in_ir, ldb, tokens, N, H, W, C, acc, hist);
   MMI_CHECK_LAUNCH("mmi_fusion_stats");
   hipLaunchKernelGGL(fusion_stats_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)acc, (const unsigned int*)hist,
                      (double)npix * C, (double)(N - 1) * H * W * C, out3);

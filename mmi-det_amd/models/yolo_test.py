@@ -254,6 +254,8 @@ class Model(nn.Module):
         """Pickling (train.py:881-899 stores whole model objects) and deepcopy (ModelEMA): HIP stream handles stay behind."""
         state = dict(self.__dict__)
         state['_ir_streams'] = {}
+        for k in ('_side_streams', '_stats_fork', '_main_stream'):
+            state.pop(k, None)
         return state
 
     def __setstate__(self, state):
@@ -332,6 +334,7 @@ class Model(nn.Module):
         fan = self._fan_skip if grad else {}
         tfan = self._twin_fan if grad else {}
         self._twin_out, self._twin_lanes = {}, {}                  # leader index -> twin tensor / its two lane views
+        self._stats_fork, self._main_stream = None, (torch.cuda.current_stream() if x.is_cuda else None)
         self._ir_used = False
         tw = self._twin_out
         y = []
@@ -420,8 +423,7 @@ class Model(nn.Module):
                         self._twin_lanes.pop(tfan[i], None)
                     else:
                         x, pt = m(T)
-                    with torch.no_grad():                          # CBM + IGM: values only (detached in the reference)
-                        st = F2.fusion_stats(T[..., 0, :], T[..., 1, :], m.last_tokens)
+                    st = self._fusion_stats(T[..., 0, :], T[..., 1, :], m.last_tokens)
                     self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
                 elif i in tfan:
                     x, alias = m(tw[lead], skip=True)
@@ -464,8 +466,7 @@ class Model(nn.Module):
                         y[k] = a
                 else:
                     x, pt = m(x)
-                with torch.no_grad():                              # CBM + IGM: values only (detached in the reference)
-                    st = F2.fusion_stats(in_rgb, in_ir, m.last_tokens)
+                st = self._fusion_stats(in_rgb, in_ir, m.last_tokens)
                 self.SSIMloss, self.Entropy_loss, self.ContrastiveValue, self.PTLoss = st[0], st[1], st[2], pt
             else:
                 kw = {}
@@ -494,9 +495,33 @@ class Model(nn.Module):
             y.append(x if i in self.save else None)
         if lanes:
             main.wait_stream(ir)
+        if self._stats_fork is not None:                           # the CBM / IGM statistics ran beside the layers after the FFM
+            torch.cuda.current_stream().wait_stream(self._stats_fork)
+            self._stats_fork = None
         self._twin_out, self._twin_lanes = {}, {}
         self.Combine_loss = self.SSIMloss                          # yolo_test.py:266-268 (detached SSIM term)
         return x, self.Combine_loss
+
+    def _fusion_stats(self, in_rgb, in_ir, tokens):
+        """CBM + IGM statistics (yolo_test.py:338-486 of the reference: SSIM, entropy, contrastive value): values only, detached in the
+        reference, and nobody reads them before the loss -- so the kernel (LDS-atomic bound: three 256-bin histograms over 52 M
+        values, ~0.25 ms at 16 x 160 x 160 x 128) leaves the critical path: it runs on a stream of its own beside the layers that
+        follow the FFM and is joined at the end of the forward.  Only when the caller's stream is the forward's main stream (a
+        fork from a lane stream would be the nested fork hipStreamEndCapture cannot take: tools/capture_probe.py)."""
+        with torch.no_grad():
+            cur = torch.cuda.current_stream() if in_rgb.is_cuda else None
+            if cur is None or os.environ.get('MMIDET_STATS_STREAM', '1') == '0' or cur != getattr(self, '_main_stream', None):
+                return F2.fusion_stats(in_rgb, in_ir, tokens)
+            side = self._side_streams.get(in_rgb.device) if hasattr(self, '_side_streams') else None
+            if side is None:
+                if not hasattr(self, '_side_streams'):
+                    self._side_streams = {}
+                side = self._side_streams[in_rgb.device] = torch.cuda.Stream(device=in_rgb.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                st = F2.fusion_stats(in_rgb, in_ir, tokens)
+            self._stats_fork = side
+            return st
 
     def _pack_for_twin(self):
         """C3's cv1 | cv2 run as one GEMM -- and the two backbones' C3 as one twin launch -- only when their parameters share

@@ -262,7 +262,7 @@ def test_yolov5l_640_train_step_matches_oracle(gemm):
     checked = 0
     for n, p in m.named_parameters():
         r = og.get(n)
-        if r is None or float(r.norm()) < 1e-9:
+        if r is None or float(r.norm()) < 1e-6 or n.endswith('key_proj.bias'):   # (key_proj.bias: mathematically zero -- softmax is shift-invariant -- so pure rounding noise)
             continue
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
         ratio = float(p.grad.norm()) / float(r.norm())
