@@ -492,6 +492,19 @@ def main():
         ms, enq = probe()
         probes['eager'] = round(ms, 1)
         probes['eager_host_enqueue'] = round(enq, 1)
+        # Backbone launch form per workload: twin launches (both backbones' layer pairs in one grid) win where launches or the
+        # host bound the step, the two-lane form (RGB / IR backbones on two HIP streams) where the other lane's GEMM hides this
+        # lane's BatchNorm passes (yolov5x at 1280: +1.4 %).  Probed like the launch mode; a switch needs a 1 % margin.
+        if getattr(model, 'twin', False) and args.storage == 'f32' and os.environ.get('MMIDET_FORM_PROBE', '1') != '0':
+            model.twin = False
+            ts.step(imgs, tg)                              # first lane-form step: its streams, workspaces and pixel tables
+            ms_l, enq_l = probe()
+            probes['eager_lanes'] = round(ms_l, 1)
+            if ms_l < 0.99 * ms:
+                ms, enq = ms_l, enq_l
+                probes['eager_host_enqueue'] = round(enq, 1)
+            else:
+                model.twin = True
         if enq > 0.92 * ms:
             ts.use_graph = True
             ts.step(imgs, tg)                             # capture (runs two eager steps on a side stream first)
