@@ -280,17 +280,68 @@ def cpu_baseline(workload, seconds_budget=25.0):
                       % (n, workload, bs, dt)}
 
 
+def _cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def plan_rank_cores(local_rank, local_world, allowed, sysfs='/sys'):
+    """Cores for one rank of `local_world` ranks on this node, out of the `allowed` ones.  Ranks whose GPU reports a NUMA node
+    (sysfs: the AMD display / accelerator PCI functions in bus order = HIP's device order) share that node's cores among the ranks
+    of the node, each an equal contiguous block; without that information the allowed cores are cut into equal contiguous blocks
+    in rank order.  Reads sysfs text files only -- nothing here touches the GPU."""
+    allowed = sorted(allowed)
+    per = len(allowed) // max(local_world, 1)
+    fallback = allowed[local_rank * per:(local_rank + 1) * per] if per >= 1 else []
+    try:
+        gpus = []
+        base = os.path.join(sysfs, 'bus', 'pci', 'devices')
+        for dev in sorted(os.listdir(base)):
+            def rd(name, dev=dev):
+                with open(os.path.join(base, dev, name)) as f:
+                    return f.read().strip()
+            try:
+                if rd('vendor') != '0x1002' or rd('class')[:4] not in ('0x03', '0x12'):   # display controller / processing accelerator
+                    continue
+                gpus.append(int(rd('numa_node')))
+            except (OSError, ValueError):
+                continue
+        vis = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('CUDA_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
+        if vis:                                           # a visible-device list renumbers the GPUs: follow it when it is numeric
+            try:
+                gpus = [gpus[int(v)] for v in vis.split(',') if v.strip() != '']
+            except (ValueError, IndexError):
+                return fallback
+        if len(gpus) < local_world or gpus[local_rank] < 0:
+            return fallback
+        node = gpus[local_rank]
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', 'node%d' % node, 'cpulist')) as f:
+            cores = [c for c in _cpulist(f.read()) if c in set(allowed)]
+        mates = [r for r in range(local_world) if gpus[r] == node]       # the ranks that share this node's cores
+        share = len(cores) // len(mates)
+        if share < 1:
+            return fallback
+        k = mates.index(local_rank)
+        return cores[k * share:(k + 1) * share]
+    except (OSError, ValueError, IndexError):
+        return fallback
+
+
 def pin_rank_to_cores(local_rank, local_world, world):
     """-> 'first-last (n cores)' description of the set this rank was pinned to, or None when nothing was changed."""
     want = os.environ.get('MMIDET_PIN', '1' if world > 1 else '0')
     if want == '0' or not hasattr(os, 'sched_setaffinity'):
         return None
     try:
-        cores = sorted(os.sched_getaffinity(0))
-        per = len(cores) // max(local_world, 1)
-        if per < 1:
+        mine = plan_rank_cores(local_rank, local_world, os.sched_getaffinity(0))
+        if not mine:
             return None
-        mine = cores[local_rank * per:(local_rank + 1) * per]
         os.sched_setaffinity(0, mine)
         return '%d-%d (%d cores)' % (mine[0], mine[-1], len(mine))
     except OSError:

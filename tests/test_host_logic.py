@@ -232,3 +232,39 @@ def _width_of(m, j):
         if isinstance(layer, SPP):
             return layer.cv2.conv.weight.shape[0]
         j = m._srcs[j][0]
+
+
+def test_rank_core_plan_follows_the_gpus_numa_nodes(tmp_path):
+    """bench.py pins each rank before the GPU is touched: ranks share the cores of their GPU's NUMA node (sysfs), equal contiguous
+    blocks; without NUMA information equal blocks of the allowed cores in rank order.  A fake sysfs tree of a two-socket, 8-GPU box."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    pci = tmp_path / 'bus' / 'pci' / 'devices'
+    for i in range(8):                                   # GPUs 0-3 on node 0, 4-7 on node 1; an unrelated device in between
+        d = pci / ('0000:%02x:00.0' % (0x10 + 0x10 * i))
+        d.mkdir(parents=True)
+        (d / 'vendor').write_text('0x1002\n')
+        (d / 'class').write_text('0x120000\n')
+        (d / 'numa_node').write_text('%d\n' % (i // 4))
+    nic = pci / '0000:05:00.0'
+    nic.mkdir()
+    (nic / 'vendor').write_text('0x15b3\n')
+    (nic / 'class').write_text('0x020000\n')
+    (nic / 'numa_node').write_text('0\n')
+    for n, cl in ((0, '0-63,128-191'), (1, '64-127,192-255')):
+        nd = tmp_path / 'devices' / 'system' / 'node' / ('node%d' % n)
+        nd.mkdir(parents=True)
+        (nd / 'cpulist').write_text(cl + '\n')
+    allowed = set(range(256))
+    plans = [bench.plan_rank_cores(r, 8, allowed, sysfs=str(tmp_path)) for r in range(8)]
+    assert all(len(p) == 32 for p in plans)
+    assert sorted(c for p in plans for c in p) == list(range(256))                  # disjoint, everything used
+    node0 = set(range(64)) | set(range(128, 192))
+    assert all(set(plans[r]) <= node0 for r in range(4)) and all(not (set(plans[r]) & node0) for r in range(4, 8))
+    # a restricted affinity mask (a container's cpuset) is respected
+    some = set(range(0, 256, 2))
+    assert all(set(bench.plan_rank_cores(r, 8, some, sysfs=str(tmp_path))) <= some for r in range(8))
+    # no GPU information (this container): equal contiguous blocks of what is allowed
+    assert bench.plan_rank_cores(1, 2, set(range(8)), sysfs=str(tmp_path / 'nothing')) == [4, 5, 6, 7]
+    assert bench._cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
