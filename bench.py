@@ -360,7 +360,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-gemm', default=None, help='write the per-shape GEMM time table of the roofline pass here')
     ap.add_argument('--ddp', action='store_true', help='run the data-parallel code path even on one GPU (world size 1)')
-    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x9', 'bf16x6', 'bf16x3'],
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x9', 'bf16x6', 'bf16x3', 'exact_auto'],
                     help='arithmetic of the conv/linear GEMMs in the TIMED region.  fp32 (default, the headline): exact fp32 '
                          'products on v_mfma_f32_32x32x2_f32.  bf16x6: every operand split into three bf16 terms, six bf16 MFMA '
                          'products of total order <= 2, fp32 accumulation (GEMM 3e-7..1e-6 vs the fp32 kernels).  bf16x9: all nine '
@@ -515,7 +515,7 @@ def main():
     from mmidet_hip import lib as _lib
     # bf16 storage: the GEMMs whose operands stay fp32 in HBM (token-side Linear layers, Focus, Detect heads) take the same
     # single-product bf16 arithmetic (mode 5 = "bf16x1")
-    _lib.set_gemm_precision(5 if args.storage == 'bf16' else {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16x9': 3}[args.gemm])
+    _lib.set_gemm_precision(5 if args.storage == 'bf16' else {'fp32': 0, 'bf16x3': 1, 'bf16x6': 2, 'bf16x9': 3, 'exact_auto': 6}[args.gemm])
     note('model on device, %d params; warmup' % sum(p.numel() for p in model.parameters()))
     for i in range(args.warmup):
         ts.step(imgs, tg)
@@ -613,7 +613,7 @@ def main():
     if args.gemm == 'fp32' and not args.no_split_probe:
         # Not the headline: the same step with the opt-in split-bf16 GEMM arithmetics, reported beside it.
         ts.use_graph = False
-        for name, mode in (('bf16x9', 3), ('bf16x6', 2), ('bf16x3', 1)):
+        for name, mode in (('exact_auto', 6), ('bf16x9', 3), ('bf16x6', 2), ('bf16x3', 1)):
             _lib.set_gemm_precision(mode)
             for _ in range(2):
                 ts.step(imgs, tg)
@@ -669,7 +669,8 @@ def main():
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16 storage + bf16 MFMA, fp32 accumulation / weights / BatchNorm statistics / loss (opt-in, NOT the parity headline)' if args.storage == 'bf16' else {'fp32': 'f32', 'bf16x9': 'f32 storage/accumulation, exact products as 9 bf16 MFMAs of a 3-term split',
                       'bf16x6': 'f32 storage/accumulation, products as 6 bf16 MFMAs of a 3-term split',
-                      'bf16x3': 'f32 storage/accumulation, products as 3 bf16 MFMAs of a 2-term split'}[args.gemm],
+                      'bf16x3': 'f32 storage/accumulation, products as 3 bf16 MFMAs of a 2-term split',
+                      'exact_auto': 'f32 storage/accumulation, every product exact: fp32 MFMA or 9 bf16 MFMAs of a 3-term split, chosen per layer shape'}[args.gemm],
             'data': 'synthetic',
             'config': {'workload': {'l_fourier': 'yolov5l two-stream-fourier (default YAML, CEM+FFM+3xGPT), nc=6',
                                     's_fourier': 'yolov5s two-stream-fourier (GPT1_fourier[64]), nc=6',
@@ -723,7 +724,10 @@ def main():
                                                 'launches_per_step': v[2] // roof_steps} for k, v in per.items()},
                                'step_algorithmic_TFLOP/s': round(3 * WORKLOADS[args.workload][6] * 1e9 * value / 1e12, 2)}
         if split:
-            what = {'bf16x9': 'three bf16 terms per operand (an exact representation of the fp32 significand), all nine products on '
+            what = {'exact_auto': 'every fp32 product exact and fp32 accumulation in every GEMM, as the headline: per layer shape and direction the '
+                                  'fp32-MFMA kernel or the nine-product bf16 kernel, whichever measured faster in the step (mmi_set_gemm_precision(6): '
+                                  '3x3 layers of >= 128 channels and the 1024 x 4096 projections take the latter)',
+                    'bf16x9': 'three bf16 terms per operand (an exact representation of the fp32 significand), all nine products on '
                               'v_mfma_f32_32x32x16_bf16, fp32 accumulation: every product exact as with the fp32 MFMA; whole-step '
                               'gradients vs the oracle as the fp32 path (medians 9e-4..1.6e-3 over four seeds at full depth)',
                     'bf16x6': 'the six products of total order <= 2 (dropped terms <= 2^-24): a GEMM differs from the fp32 kernel by '
@@ -739,9 +743,9 @@ def main():
                        # MFMA rate, MI355X_MICROARCH.md) divided by the bf16 products one fp32 product costs in this mode
                        'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s (fp32-equivalent, whole step)',
                                     'achieved': round(3 * WORKLOADS[args.workload][6] * 1e9 * world * bs / v[0] / 1e12, 2),
-                                    'peak': round(16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:]), 1),
+                                    'peak': round(16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:]), 1) if k.startswith('bf16x') else None,
                                     'frac': round(3 * WORKLOADS[args.workload][6] * 1e9 * world * bs / v[0] / 1e12
-                                                  / (16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:])), 4)}} for k, v in split.items()}}
+                                                  / (16 * PEAK_FP32_MFMA_TFLOPS / int(k[5:])), 4) if k.startswith('bf16x') else None}} for k, v in split.items()}}
         if pcie is not None:
             out['pcie_inclusive'] = pcie
         if not args.no_roofline and args.workload != 's_add':

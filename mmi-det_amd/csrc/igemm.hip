@@ -69,6 +69,19 @@ int check_desc(const mmi_conv_desc* d, const char* who) {
   MMI_CHECK_ARG((int64_t)d->N * d->H * d->W < (1LL << 31) && (int64_t)d->KH * d->KW * d->Cin < (1 << 24), "%s: size overflow", who);
   return MMI_OK;
 }
+int pick_exact_prec(const mmi_conv_desc* d, int dir) {
+  if (d == nullptr || d->Cin % 32 != 0 || d->Cout % 32 != 0) return 0;     // (the nine-product kernels want the uniform-tap / pixel-table loaders)
+  const int64_t kk = (int64_t)d->Cin * d->Cout;
+  if (d->KH == 3) {
+    if (d->Cin >= 128) return 3;                     // every direction of the 128..1024-channel 3x3 layers
+    return dir == 1 ? 3 : 0;                         // 64-channel 3x3 at 160x160: the data gradient only
+  }
+  return kk >= (1 << 22) && dir != 2 ? 3 : 0;        // the large token-side projections (1024 x 4096 ...), forward and data gradient
+}
+PrecScope::PrecScope(const mmi_conv_desc* d, int dir) : saved(g_gemm_prec) {
+  if (saved == 6) g_gemm_prec = pick_exact_prec(d, dir);
+}
+PrecScope::~PrecScope() { g_gemm_prec = saved; }
 }  // namespace mmi_ig
 using namespace mmi_ig;
 
@@ -165,8 +178,8 @@ FwdPlan dgrad_plan(const mmi_conv_desc* d, int nprob = 1) {
 }  // namespace
 
 extern "C" int mmi_set_gemm_precision(int mode) {
-  MMI_CHECK_ARG((mode >= 0 && mode <= 3) || mode == 5,
-                "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9, 5 = bf16x1)", mode);
+  MMI_CHECK_ARG((mode >= 0 && mode <= 3) || mode == 5 || mode == 6,
+                "mmi_set_gemm_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6, 3 = bf16x9, 5 = bf16x1, 6 = exact: 0 or 3 per shape)", mode);
   g_gemm_prec = mode;
   return MMI_OK;
 }
@@ -229,17 +242,20 @@ extern "C" int mmi_set_streamk_slots(int slots) {
 }
 
 extern "C" int mmi_conv_fwd_row_blocks(const mmi_conv_desc* d) {
+  const PrecScope prec_scope_(d, 0);
   if (check_desc(d, "mmi_conv_fwd_row_blocks") != MMI_OK) return MMI_ERR_ARG;
   if (mmi_smallconv_supported(d)) return mmi_smallconv_blocks(d);  // CEM layers: direct VALU conv (cem.hip)
   return fwd_plan(d).mtiles;
 }
 
 extern "C" size_t mmi_conv_fwd_workspace(const mmi_conv_desc* d) {
+  const PrecScope prec_scope_(d, 0);
   if (check_desc(d, "mmi_conv_fwd_workspace") != MMI_OK || mmi_smallconv_supported(d)) return 0;
   return fwd_workspace_bytes(fwd_plan(d), d->Cout);
 }
 
 extern "C" size_t mmi_conv_dgrad_workspace(const mmi_conv_desc* d) {
+  const PrecScope prec_scope_(d, 1);
   if (check_desc(d, "mmi_conv_dgrad_workspace") != MMI_OK || mmi_smallconv_dgrad_supported(d)) return 0;
   return sk_workspace_bytes(dgrad_plan(d));
 }
@@ -248,6 +264,7 @@ namespace {
 int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* residual, int ldr, int act, float* y,
                   float* stat_partials, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream,
                   const char* who, const mmi_bn_stats* bn = nullptr) {
+  const PrecScope prec_scope_(d, 0);
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(x && w && y, "%s: null pointer", who);
   MMI_CHECK_ARG(!(bias && stat_partials), "%s: bias and BN statistics are mutually exclusive", who);
@@ -343,6 +360,7 @@ int fill_epilogue(IgemmP& p, const mmi_conv_desc* d, const mmi_linear_epilogue* 
 extern "C" int mmi_linear_fwd_fused(const float* x, const float* w, const float* bias, float* y, void* workspace,
                                     size_t workspace_bytes, const mmi_conv_desc* d, const mmi_linear_epilogue* e,
                                     void* stream) {
+  const PrecScope prec_scope_(d, 0);
   if (int err = check_desc(d, "mmi_linear_fwd_fused")) return err;
   MMI_CHECK_ARG(x && w && y, "mmi_linear_fwd_fused: null pointer");
   const bool vec = fwd_vec(d);
@@ -360,6 +378,7 @@ extern "C" int mmi_linear_fwd_fused(const float* x, const float* w, const float*
 
 extern "C" int mmi_linear_dgrad_fused(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                                       const mmi_conv_desc* d, const mmi_linear_epilogue* e, void* stream) {
+  const PrecScope prec_scope_(d, 1);
   if (int err = check_desc(d, "mmi_linear_dgrad_fused")) return err;
   MMI_CHECK_ARG(dy && w && dx, "mmi_linear_dgrad_fused: null pointer");
   const bool vec = dgrad_vec(d);
@@ -392,6 +411,7 @@ extern "C" int mmi_conv_bias_act_fwd(const float* x, const float* w, const float
 
 extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                               const mmi_conv_desc* d, void* stream) {
+  const PrecScope prec_scope_(d, 1);
   if (int e = check_desc(d, "mmi_conv_dgrad")) return e;
   MMI_CHECK_ARG(dy && w && dx, "mmi_conv_dgrad: null pointer");
   if (mmi_smallconv_dgrad_supported(d)) return mmi_smallconv_dgrad(dy, w, dx, d, (hipStream_t)stream);
@@ -438,17 +458,20 @@ bool twin_shape_ok(const mmi_conv_desc* d) { return !mmi_smallconv_supported(d) 
 }  // namespace
 
 extern "C" int mmi_conv_fwd_row_blocks_n(const mmi_conv_desc* d, int nprob) {
+  const PrecScope prec_scope_(d, 0);
   if (check_desc(d, "mmi_conv_fwd_row_blocks_n") != MMI_OK || nprob < 1 || nprob > 2) return MMI_ERR_ARG;
   return fwd_plan(d, nprob).mtiles;
 }
 
 extern "C" size_t mmi_conv_fwd_workspace_n(const mmi_conv_desc* d, int nprob) {
+  const PrecScope prec_scope_(d, 0);
   if (check_desc(d, "mmi_conv_fwd_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || !twin_shape_ok(d)) return 0;
   if (nprob == 1) return fwd_workspace_bytes(fwd_plan(d, 1), d->Cout);
   return 2 * WS_HEADER_BYTES + 2 * twin_body_bytes(fwd_plan(d, 2), d->Cout);
 }
 
 extern "C" size_t mmi_conv_dgrad_workspace_n(const mmi_conv_desc* d, int nprob) {
+  const PrecScope prec_scope_(d, 1);
   if (check_desc(d, "mmi_conv_dgrad_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || !twin_shape_ok(d)) return 0;
   if (nprob == 1) return sk_workspace_bytes(dgrad_plan(d, 1));
   const FwdPlan f = dgrad_plan(d, 2);
@@ -458,6 +481,7 @@ extern "C" size_t mmi_conv_dgrad_workspace_n(const mmi_conv_desc* d, int nprob) 
 extern "C" int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, float* const* y, float* const* stat_partials,
                                 const mmi_bn_stats* bn, int mi_stride, void* workspace, size_t workspace_bytes,
                                 const mmi_conv_desc* d, void* stream) {
+  const PrecScope prec_scope_(d, 0);
   const char* who = "mmi_conv_bn_fwd2";
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(x && w && y && stat_partials && bn, "%s: null argument arrays", who);
@@ -498,6 +522,7 @@ extern "C" int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, fl
 // dx[g] = conv_transpose(dy[g], w[g]) [+ skip[g]]; skip (row stride ldskip) only for 1x1 stride-1 layers (GEMM epilogue), else NULL
 extern "C" int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
                                void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  const PrecScope prec_scope_(d, 1);
   const char* who = "mmi_conv_dgrad2";
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(dy && w && dx, "%s: null argument arrays", who);

@@ -117,6 +117,17 @@ struct WgPlan {
   bool vec;
 };
 
+// Mode 6 of mmi_set_gemm_precision ("exact, fastest kernel per shape"): every entry point that plans or launches a GEMM holds a
+// PrecScope, which replaces the global mode by 0 (fp32 MFMA) or 3 (nine bf16 products) for the duration of the call -- both forms
+// make every fp32 product exactly and accumulate in fp32 -- by a rule on the layer's shape and direction (0 fwd, 1 dgrad, 2 wgrad)
+// taken from the per-shape in-step timings of the two modes (profiles/r04_gemm_by_shape_fp32_vs_bf16x9.txt).
+int pick_exact_prec(const mmi_conv_desc* d, int dir);
+struct PrecScope {
+  int saved;
+  PrecScope(const mmi_conv_desc* d, int dir);
+  ~PrecScope();
+};
+
 // planner / tuning state (igemm.hip)
 extern int g_uniform_loaders, g_gemm_prec, g_tile_bm, g_tile_bn, g_wgrad_force[3], g_sk_slots;
 const float* zero_src();   // 16 zero bytes in device memory: the source of masked lanes (see the loaders)

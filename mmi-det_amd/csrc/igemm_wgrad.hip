@@ -804,6 +804,7 @@ WgPlan wgrad_plan(const mmi_conv_desc* d, int nprob = 1) {
 // Workspace of a wgrad launch: [0, WG_COUNTER_BYTES) per-tile arrival counters of the in-launch split-K fold (zero-filled
 // when first handed over, self-cleaning afterwards), then the splits' partial slabs (no zero-fill needed).
 extern "C" size_t mmi_conv_wgrad_workspace(const mmi_conv_desc* d) {
+  const PrecScope prec_scope_(d, 2);
   if (check_desc(d, "mmi_conv_wgrad_workspace") != MMI_OK) return 0;
   const WgPlan g = wgrad_plan(d);
   const size_t generic = g.splits > 1 ? (size_t)g.splits * ((size_t)d->Cout * d->KH * d->KW * d->Cin + d->Cout) * sizeof(float) : 0;
@@ -826,6 +827,7 @@ int64_t wgrad_table_entries(const mmi_conv_desc* d) { return (int64_t)d->N * d->
 }  // namespace
 
 extern "C" size_t mmi_conv_wgrad_table_bytes(const mmi_conv_desc* d) {
+  const PrecScope prec_scope_(d, 2);
   if (check_desc(d, "mmi_conv_wgrad_table_bytes") != MMI_OK || !wgrad_uses_table(d)) return 0;
   return (size_t)wgrad_table_entries(d) * sizeof(uint2);
 }
@@ -864,6 +866,7 @@ extern "C" int mmi_conv_wgrad_tab(const float* dy, const float* x, float* dw, fl
 // twin form (see igemm.hip, "twin launches"): two problems of one shape in one launch; dbias may be NULL (or hold NULLs);
 // workspace = mmi_conv_wgrad_workspace_n(d, 2) bytes, 256-byte aligned; the pixel table (shapes only) serves both
 extern "C" size_t mmi_conv_wgrad_workspace_n(const mmi_conv_desc* d, int nprob) {
+  const PrecScope prec_scope_(d, 2);
   if (check_desc(d, "mmi_conv_wgrad_workspace_n") != MMI_OK || nprob < 1 || nprob > 2 || mmi_smallconv_supported(d)) return 0;
   if (nprob == 1) return wgrad_ws_one(d, wgrad_plan(d, 1));
   const size_t one = wgrad_ws_one(d, wgrad_plan(d, 2));
@@ -879,6 +882,7 @@ extern "C" int mmi_conv_wgrad2(const float* const* dy, const float* const* x, fl
 namespace {
 int conv_wgrad_n(int nprob, const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,
                  size_t workspace_bytes, const void* table, const mmi_conv_desc* d, void* stream, bool bf16_io) {
+  const PrecScope prec_scope_(d, 2);
   if (int e = check_desc(d, "mmi_conv_wgrad")) return e;
   for (int q = 0; q < nprob; ++q) MMI_CHECK_ARG(dy[q] && x[q] && dw[q], "mmi_conv_wgrad: null pointer");
   const bool want_bias = dbias[0] != nullptr;
