@@ -31,7 +31,7 @@ stats = {'allocs': 0, 'checked': 0, 'checks': 0}
 
 def _site():
     for fr in reversed(traceback.extract_stack(limit=8)[:-3]):
-        if not fr.filename.endswith('alloc.py'):
+        if os.path.basename(fr.filename) != 'alloc.py':
             return '%s:%d' % (os.path.basename(fr.filename), fr.lineno)
     return '?'
 
