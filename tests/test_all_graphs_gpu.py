@@ -90,3 +90,16 @@ def test_graph_matches_the_oracle(name):
     for k, v in osd.items():
         if k.endswith('running_mean') or k.endswith('running_var'):
             close(msd[k], v, what=k, tol=1e-4)
+    # evaluation mode on the updated running statistics: the decoded detections and the raw head outputs (test.py:123-139), and
+    # again after Model.fuse() (BatchNorm folded into the convolutions, the lane form instead of twin launches)
+    m.eval()
+    o.eval()
+    with torch.no_grad():
+        (zo, po_e), _ = o(x[:, :3], x[:, 3:])
+        (zg, pg_e), _ = m(xd[:, :3], xd[:, 3:])
+        close(zg, zo, what='eval: decoded detections')
+        for i in range(len(po_e)):
+            close(pg_e[i], po_e[i], what='eval: head output %d' % i)
+        m.fuse()
+        (zf, _), _ = m(xd[:, :3], xd[:, 3:])
+        close(zf, zo, what='eval after fuse(): decoded detections', tol=2e-3)
