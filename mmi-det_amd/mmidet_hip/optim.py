@@ -55,21 +55,26 @@ def _same_layout(a, b):
     return all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
 
 
-class FusedSGDEMA:
+class FusedSGDEMA(torch.optim.Optimizer):
+    """A torch.optim.Optimizer (so that the reference's `lr_scheduler.LambdaLR(optimizer, ...)`, `GradScaler.step(optimizer)`,
+    `optimizer.state_dict()` into the checkpoint and `optimizer.load_state_dict(ckpt['optimizer'])` on resume -- train.py:597,
+    800, 888, 609 -- work unchanged) whose step is the one fused launch.  State layout = torch.optim.SGD's
+    (`state[p]['momentum_buffer']`), so checkpoints move between the two optimizers."""
     TAIL_PREFIX = 'Enhance.'     # state_dict prefix of the modules whose backward runs last (models/yolo_test.py: self.Enhance)
 
     def __init__(self, model, groups, ema_model=None, ema_decay=0.9999, ema_updates=0):
         """groups: list of dicts {'params': [...], 'lr':, 'momentum':, 'weight_decay':} (at most 3)."""
         assert 1 <= len(groups) <= 3
-        self.param_groups = groups
         for g in groups:
             g.setdefault('initial_lr', g['lr'])
             g.setdefault('weight_decay', 0.0)
             g.setdefault('nesterov', True)
+            g.setdefault('dampening', 0)
+        super().__init__(groups, dict(lr=groups[0]['lr'], momentum=groups[0]['momentum'], weight_decay=0.0, nesterov=True, dampening=0))
         self.model, self.ema_model = model, ema_model
         self.ema_decay, self.updates = ema_decay, ema_updates
         self.device = next(model.parameters()).device
-        self.state = {}        # param -> momentum buffer (same memory layout as the parameter)
+        self._bufs = {}        # param -> momentum buffer (same memory layout as the parameter; also state[p]['momentum_buffer'])
         self._steps = 0
         self._gptrs = None
         self._recs_host = self._recs_dev = self._chunks_dev = None
@@ -95,7 +100,8 @@ class FusedSGDEMA:
                 if not p.requires_grad:
                     continue
                 buf = torch.zeros_like(p, memory_format=torch.preserve_format)
-                self.state[p] = buf
+                self._bufs[p] = buf
+                self.state[p]['momentum_buffer'] = buf
                 e = ema_of.get(p.data_ptr())
                 rows.append([p.data_ptr(), 0, buf.data_ptr(), e.data_ptr() if e is not None else 0, p.numel(), gi,
                              1 | (2 if e is not None else 0)])
@@ -186,9 +192,26 @@ class FusedSGDEMA:
                              _stream() if stream is None else stream)
         return True
 
-    def step(self):
+    def step(self, closure=None):
+        assert closure is None, 'FusedSGDEMA.step takes no closure'
         self.upload_hyper()
         self.launch()
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the state tensors by copies; the kernel's pointer table holds the addresses of the buffers made
+        at construction, so the loaded momenta are copied INTO those (layout conversion included) and the state points back at
+        them.  A state with momenta means steps have been taken: the kernel's first-step form (buffer = gradient) is over."""
+        super().load_state_dict(state_dict)
+        loaded = False
+        with torch.no_grad():
+            for p, buf in self._bufs.items():
+                mb = self.state[p].get('momentum_buffer') if p in self.state else None
+                if mb is not None and mb.data_ptr() != buf.data_ptr():
+                    buf.copy_(mb)
+                    loaded = True
+                self.state[p]['momentum_buffer'] = buf
+        if loaded:
+            self._steps = max(self._steps, 1)
 
     def zero_grad(self, set_to_none=True):
         for p in self._sgd_params:

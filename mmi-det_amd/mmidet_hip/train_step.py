@@ -196,6 +196,8 @@ class TrainStep:
             self.optimizer.step()
             if self.ema is not None:
                 self.ema.update(self.model)
+        if self.fused and self.ema is not None:
+            self.ema.updates = self.optimizer.updates                                   # (what train.py:892 stores as 'updates')
         if self.reducer is not None:
             self.reducer.zero(keep_grads=in_capture)                                    # grads are views of flat buckets
         else:
@@ -214,6 +216,32 @@ class TrainStep:
         if self.ni % self.accumulate == 0:
             self._update()
         return loss, items
+
+    # ---- checkpoint / resume (train.py:881-899 writes, 521-531 + 603-615 read) -----------------------------------------------
+    def checkpoint(self):
+        """The reference's checkpoint dictionary for this trainer: whole model objects as train.py stores them (models/experimental.
+        attempt_load reads them back), the EMA update count, the optimizer state in torch.optim.SGD's format."""
+        from copy import deepcopy
+        torch.cuda.synchronize()
+        return {'model': deepcopy(self.model), 'ema': deepcopy(self.ema.ema) if self.ema is not None else None,
+                'updates': self.ema.updates if self.ema is not None else 0, 'optimizer': self.optimizer.state_dict(), 'ni': self.ni}
+
+    def resume(self, ckpt):
+        """Continue from checkpoint(): weights and buffers IN PLACE (the kernels' pointer tables stay valid), EMA, momenta, counters."""
+        assert self._graph is None, 'resume before the step graph is captured'
+        with torch.no_grad():
+            for dst, src in ((self.model, ckpt['model']), (self.ema.ema if self.ema is not None else None, ckpt.get('ema'))):
+                if dst is None or src is None:
+                    continue
+                ssd = src.state_dict()
+                for k, v in dst.state_dict().items():
+                    v.copy_(ssd[k])
+        self.optimizer.load_state_dict(ckpt['optimizer'])
+        if self.ema is not None:
+            self.ema.updates = ckpt.get('updates', 0)
+            if self.fused:
+                self.optimizer.updates = self.ema.updates
+        self.ni = ckpt.get('ni', 0)
 
     # ---- whole-step hipGraph -----------------------------------------------------------------------------------------------
     def _graph_step(self, imgs_u8, targets):

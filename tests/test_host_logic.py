@@ -268,3 +268,37 @@ def test_rank_core_plan_follows_the_gpus_numa_nodes(tmp_path):
     # no GPU information (this container): equal contiguous blocks of what is allowed
     assert bench.plan_rank_cores(1, 2, set(range(8)), sysfs=str(tmp_path / 'nothing')) == [4, 5, 6, 7]
     assert bench._cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_fused_optimizer_is_a_torch_optimizer_with_sgd_compatible_state():
+    """train.py:597 (LambdaLR(optimizer)), 888 (optimizer.state_dict() into the checkpoint), 609 (load_state_dict on resume): the
+    fused optimizer takes the scheduler, and its state moves to and from torch.optim.SGD(nesterov).  Host side only (no step)."""
+    from mmidet_hip.optim import FusedSGDEMA
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5))
+    groups = [dict(params=[net[1].weight], lr=0.01, momentum=0.9, weight_decay=0.0),
+              dict(params=[net[0].weight], lr=0.02, momentum=0.9, weight_decay=5e-4),
+              dict(params=[net[0].bias, net[1].bias], lr=0.1, momentum=0.9, weight_decay=0.0)]
+    opt = FusedSGDEMA(net, groups)
+    assert isinstance(opt, torch.optim.Optimizer) and opt.param_groups[1] is groups[1]
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: 0.5)
+    assert [g['lr'] for g in opt.param_groups] == [0.005, 0.01, 0.05] and sch is not None
+    ref = torch.optim.SGD([net[1].weight], lr=0.01, momentum=0.9, nesterov=True)
+    ref.add_param_group({'params': [net[0].weight], 'weight_decay': 5e-4})
+    ref.add_param_group({'params': [net[0].bias, net[1].bias]})
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ptr = {p: b.data_ptr() for p, b in opt._bufs.items()}
+    opt.load_state_dict(ref.state_dict())
+    assert opt._steps == 1                                   # momenta loaded: the first-step form of the kernel is over
+    for p, b in opt._bufs.items():
+        assert b.data_ptr() == ptr[p] and opt.state[p]['momentum_buffer'] is b        # the kernel's addresses did not move
+        assert torch.equal(b, ref.state[p]['momentum_buffer'])
+    assert [g['weight_decay'] for g in opt.param_groups] == [0, 5e-4, 0]
+    ref2 = torch.optim.SGD([net[1].weight], lr=0.01, momentum=0.9, nesterov=True)
+    ref2.add_param_group({'params': [net[0].weight], 'weight_decay': 5e-4})
+    ref2.add_param_group({'params': [net[0].bias, net[1].bias]})
+    ref2.load_state_dict(opt.state_dict())                   # and back
+    for p in net.parameters():
+        assert torch.equal(ref2.state[p]['momentum_buffer'], ref.state[p]['momentum_buffer'])

@@ -523,3 +523,63 @@ def test_model_ema_packs_its_copy_at_construction():
     m(x[:, :3], x[:, 3:])
     c3m = next(mod for mod in m.modules() if type(mod).__name__ == 'C3')
     assert back_to_back(c3m.cv1.conv.weight.data, c3m.cv2.conv.weight.data)   # first training forward packs
+
+
+def test_checkpoint_and_resume_continue_the_same_training():
+    """train.py:881-899 / 521-531, 603-615: 3 steps, checkpoint, 2 more == a fresh trainer resumed from the checkpoint + the same 2
+    steps, bit for bit (weights, BatchNorm buffers, EMA, momenta, counters); the checkpoint's optimizer state is torch.optim.SGD's."""
+    m1, ts1, cfg = make()
+    batches = [batch(cfg, 60 + i) for i in range(5)]
+    for imgs, tg in batches[:3]:
+        ts1.step(imgs, tg)
+    ck = ts1.checkpoint()
+    assert ck['updates'] == 3 and ck['ni'] == 3 and set(ck['optimizer']) == {'state', 'param_groups'}
+    assert all('momentum_buffer' in v for v in ck['optimizer']['state'].values())
+    for imgs, tg in batches[3:]:
+        ts1.step(imgs, tg)
+    m2, ts2, _ = make()
+    ts2.resume(ck)
+    for imgs, tg in batches[3:]:
+        ts2.step(imgs, tg)
+    torch.cuda.synchronize()
+    for a, b, what in ((m1.state_dict(), m2.state_dict(), 'model'), (ts1.ema.ema.state_dict(), ts2.ema.ema.state_dict(), 'ema')):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (what, k)
+    for p1, p2 in zip(ts1.optimizer._sgd_params, ts2.optimizer._sgd_params):
+        assert torch.equal(ts1.optimizer._bufs[p1], ts2.optimizer._bufs[p2])
+    assert ts1.ema.updates == ts2.ema.updates == 5 and ts1.ni == ts2.ni == 5
+
+
+def test_fused_optimizer_continues_a_torch_sgd_state():
+    """A momentum state written by torch.optim.SGD(nesterov) (a reference checkpoint) loaded into the fused optimizer: the next
+    step equals torch's own next step."""
+    from mmidet_hip.optim import FusedSGDEMA
+    d = dev()
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Linear(7, 4099)).to(d)
+    net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+    ref = copy.deepcopy(net)
+
+    def groups(n):
+        return [dict(params=[n[1].weight], lr=0.01, momentum=0.937, weight_decay=0.0),
+                dict(params=[n[0].weight, n[2].weight], lr=0.02, momentum=0.937, weight_decay=5e-4),
+                dict(params=[n[0].bias, n[1].bias, n[2].bias], lr=0.1, momentum=0.937, weight_decay=0.0)]
+    ropt = torch.optim.SGD([ref[1].weight], lr=0.01, momentum=0.937, nesterov=True)
+    ropt.add_param_group({'params': [ref[0].weight, ref[2].weight], 'lr': 0.02, 'weight_decay': 5e-4})
+    ropt.add_param_group({'params': [ref[0].bias, ref[1].bias, ref[2].bias], 'lr': 0.1})
+    gs = [[torch.randn_like(p) for p in net.parameters()] for _ in range(3)]
+    for g in gs[:2]:                                              # two steps of the torch optimizer alone
+        for q, gg in zip(ref.parameters(), g):
+            q.grad = gg.clone(memory_format=torch.preserve_format)
+        ropt.step()
+    with torch.no_grad():
+        for p, q in zip(net.parameters(), ref.parameters()):
+            p.copy_(q)
+    opt = FusedSGDEMA(net, groups(net))
+    opt.load_state_dict(ropt.state_dict())
+    for p, q, gg in zip(net.parameters(), ref.parameters(), gs[2]):
+        p.grad, q.grad = gg.clone(memory_format=torch.preserve_format), gg.clone(memory_format=torch.preserve_format)
+    opt.step()
+    ropt.step()
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        close(p, q, what=n, tol=1e-6)
