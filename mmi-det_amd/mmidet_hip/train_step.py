@@ -224,7 +224,9 @@ class TrainStep:
         from copy import deepcopy
         torch.cuda.synchronize()
         return {'model': deepcopy(self.model), 'ema': deepcopy(self.ema.ema) if self.ema is not None else None,
-                'updates': self.ema.updates if self.ema is not None else 0, 'optimizer': self.optimizer.state_dict(), 'ni': self.ni}
+                'updates': self.ema.updates if self.ema is not None else 0,
+                'optimizer': deepcopy(self.optimizer.state_dict()),      # (state_dict() hands out the live momentum buffers)
+                'ni': self.ni}
 
     def resume(self, ckpt):
         """Continue from checkpoint(): weights and buffers IN PLACE (the kernels' pointer tables stay valid), EMA, momenta, counters."""
