@@ -115,7 +115,13 @@ class FusedSGDEMA(torch.optim.Optimizer):
         for i, r in enumerate(rows):
             rec[i] = tuple(r)
         self._recs_host = rec
+        key_of = {}
+        for k, v in msd.items():
+            key_of.setdefault(v.data_ptr(), k)
+        self._row_keys = [key_of.get(r[0], '') for r in rows]       # state_dict key of every record (set_parts partitions by it)
         chunks = [(i, c) for i, r in enumerate(rows) for c in range((r[4] + _CHUNK - 1) // _CHUNK)]
+        self._chunks_host = chunks
+        self._parts = None
         ck = np.array(chunks, dtype=np.int32).reshape(-1, 2)
         self._nchunks = len(chunks)
         self._chunks_dev = torch.from_numpy(ck).to(self.device)
@@ -191,6 +197,45 @@ class FusedSGDEMA(torch.optim.Optimizer):
             lib.sgd_ema_step(self._recs_dev.data_ptr(), ck.data_ptr(), n, self._hyper_dev.data_ptr(),
                              _stream() if stream is None else stream)
         return True
+
+    # ---- launch parts (TrainStep's early optimizer, generalised): the records in `nparts` groups launched in order, each as soon
+    # as the gradients of its parameters exist ------------------------------------------------------------------------------
+    def set_parts(self, part_of_key, nparts):
+        """part_of_key: state_dict key -> 0 .. nparts-1 (the order in which the parts' gradients complete in backward)."""
+        rp = np.array([int(part_of_key(k)) for k in self._row_keys], dtype=np.int32)
+        assert rp.min() >= 0 and rp.max() < nparts
+        self._sgd_part = [int(rp[i]) for i in range(len(self._sgd_params))]      # (the SGD records are the first rows, in order)
+        self._parts = []
+        for q in range(nparts):
+            sel = [c for c in self._chunks_host if rp[c[0]] == q]
+            arr = np.array(sel, dtype=np.int32).reshape(-1, 2)
+            self._parts.append((torch.from_numpy(arr).to(self.device) if len(sel) else None, len(sel)))
+
+    def refresh_upto(self, upto):
+        """Point the table at this step's gradients of the parts 0 .. upto (later parts keep the pointers they have: nobody reads
+        them yet).  False when one of the needed gradients does not exist yet."""
+        ptrs = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self._sgd_params)
+        if any(gp == 0 and q <= upto for gp, q in zip(ptrs, self._sgd_part)):
+            return False
+        old = self._gptrs or (0,) * len(ptrs)
+        ptrs = tuple(gp if q <= upto else og for gp, q, og in zip(ptrs, self._sgd_part, old))
+        if ptrs == self._gptrs:
+            return True
+        self._gptrs = ptrs
+        rec = self._recs_host
+        n = len(ptrs)
+        rec['g'][:n] = np.array(ptrs, dtype=np.uint64)
+        al = ((rec['p'] | rec['g'] | rec['buf'] | rec['ema']) & np.uint64(15)) == 0
+        rec['flags'] = (rec['flags'] & ~np.int32(4)) | np.where(al, 4, 0).astype(np.int32)
+        self._recs_stage.upload(torch.from_numpy(rec.view(np.uint8).reshape(-1)), self._recs_dev)
+        return True
+
+    def launch_parts(self, first, last, stream=None):
+        for q in range(first, last + 1):
+            ck, n = self._parts[q]
+            if n:
+                lib.sgd_ema_step(self._recs_dev.data_ptr(), ck.data_ptr(), n, self._hyper_dev.data_ptr(),
+                                 _stream() if stream is None else stream)
 
     def step(self, closure=None):
         assert closure is None, 'FusedSGDEMA.step takes no closure'

@@ -105,6 +105,14 @@ class TrainStep:
         self.early_opt = os.environ.get('MMIDET_EARLY_OPT', '0') == '1'
         self._opt_stream = None
         self._head_launched = False
+        # Generalised (MMIDET_OPT_PARTS=n, n >= 2): the records in n parts by the order their gradients complete in backward
+        # (head / neck and the P5 transformer first ... the stems and the CEM last); tensor hooks on the outputs of n - 1 layers
+        # launch every part whose gradients are complete on the optimizer's own stream, next to the MFMA-bound rest of the backward.
+        self.opt_parts = int(os.environ.get('MMIDET_OPT_PARTS', '0'))
+        self._parts_launched = 0
+        self._part_hooks = {}
+        if self.opt_parts >= 2 and self.fused and reducer is None and hasattr(model, 'model'):
+            self._plan_parts(self.opt_parts)
 
     # ---- the step body (eager; also what gets captured) ----------------------------------------------------------------
     def _body(self, imgs_u8, targets, reduce=True):
@@ -124,11 +132,17 @@ class TrainStep:
             rgb, ir = imgs[:, :3], imgs[:, 3:]                                          # train.py:744-745 (strided views)
         early = (self.early_opt and defer and self.fused and self.reducer is None and self.accumulate == 1 and imgs_u8.is_cuda
                  and not torch.cuda.is_current_stream_capturing() and getattr(model, 'two_streams', False))
+        parts = (bool(self._part_hooks) and not early and defer and self.fused and self.reducer is None and self.accumulate == 1
+                 and imgs_u8.is_cuda and not torch.cuda.is_current_stream_capturing())
         model._tail_hook = self._on_tail_gradient if early else None                    # registered on the CEM's output in forward
+        model._grad_hooks = self._part_hooks if parts else None                         # layer index -> hook on that layer's output
+        self._parts_launched = 0
+        self._parts_on = parts
         try:
             pred, comb = model(rgb, ir)                                                 # train.py:788
         finally:
             model._tail_hook = None
+            model._grad_hooks = None
         loss, items = self.compute_loss(pred, targets, comb.reshape(-1))                # train.py:789 (+ B2 reshape)
         if self.world_size > 1:
             loss = loss * self.world_size                                               # train.py:790-791
@@ -176,6 +190,67 @@ class TrainStep:
         self._head_launched = True
         return None
 
+    def _plan_parts(self, nparts):
+        """Parts by execution order: layer j runs at position pos(j) = its twin leader's index if it is a follower, else j (a pair
+        that falls back to the lane form runs LATER than planned, i.e. its gradients come earlier: still safe).  The hook on the
+        output of layer t fires when every autograd node created after it has run, i.e. when the gradients of all layers with
+        pos > t are complete (the engine pops ready nodes in descending sequence number).  Cuts are placed so that the parts hold
+        about equal parameter counts, counted from the end of the forward; only single-tensor Conv / C3 outputs carry hooks."""
+        model = self.model
+        leader = getattr(model, '_leader_of', {}) if getattr(model, 'twin', False) else {}
+        pos = {m.i: leader.get(m.i, m.i) for m in model.model}
+        count = {}
+        for m in model.model:
+            count[pos[m.i]] = count.get(pos[m.i], 0) + sum(p.numel() for p in m.parameters())
+        total = sum(count.values())
+        ok = {m.i for m in model.model if type(m).__name__ in ('Conv', 'C3') and m.i not in leader}
+        cuts, acc, want = [], 0, 1
+        for t in sorted(count, reverse=True):             # t: candidate hook layer; acc = parameters of the layers with pos > t
+            if want < nparts and acc >= want * total / nparts and t in ok:
+                cuts.append(t)
+                want += 1
+            acc += count[t]
+        if not cuts:
+            return
+        self._cuts = cuts                                  # descending layer indices: part q = layers with cuts[q] < pos <= cuts[q-1]
+
+        def part_of_key(k):
+            if not k.startswith('model.'):
+                return len(cuts)                           # the CEM and anything outside the layer list: the last part
+            p = pos.get(int(k.split('.')[1]), 0)
+            for q, t in enumerate(cuts):
+                if p > t:
+                    return q
+            return len(cuts)
+        self.optimizer.set_parts(part_of_key, len(cuts) + 1)
+        self._part_hooks = {t: self._make_part_hook(q) for q, t in enumerate(cuts)}
+
+    def _make_part_hook(self, part):
+        def hook(grad):
+            if not self._parts_on or part < self._parts_launched:
+                return None
+            opt = self.optimizer
+            cur = torch.cuda.current_stream()
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream(device=grad.device)
+            side = self._opt_stream
+            side.wait_stream(cur)                            # lane gradients, BatchNorm vectors
+            side.wait_stream(self.model._ir_stream(grad.device))
+            for sd in ops.side_streams_in_flight():          # weight gradients of the layers already walked
+                side.wait_stream(sd)
+            with torch.cuda.stream(side):                    # table and hyper-parameter uploads behind the earlier parts' launches
+                if self._parts_launched == 0:
+                    opt.upload_hyper()
+                if not opt.refresh_upto(part):
+                    if self._parts_launched == 0:            # a gradient is not there yet: leave everything to _update
+                        opt.updates -= 1
+                        opt._steps -= 1
+                    return None
+                opt.launch_parts(self._parts_launched, part, side.cuda_stream)
+            self._parts_launched = part + 1
+            return None
+        return hook
+
     def _named_params(self):
         if getattr(self, '_np_cache', None) is None:
             self._np_cache = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
@@ -190,6 +265,12 @@ class TrainStep:
                 self.optimizer.launch_part('tail')
                 torch.cuda.current_stream().wait_stream(self._opt_stream)
                 self._head_launched = False
+            elif getattr(self, '_parts_on', False) and self._parts_launched > 0:
+                # the rest (the stems, the CEM) behind the parts already launched: same stream order as their table uploads
+                torch.cuda.current_stream().wait_stream(self._opt_stream)
+                assert self.optimizer.refresh_upto(len(self.optimizer._parts) - 1), 'a parameter of an optimiser group has no gradient'
+                self.optimizer.launch_parts(self._parts_launched, len(self.optimizer._parts) - 1)
+                self._parts_launched = 0
             else:
                 self.optimizer.step()
         else:

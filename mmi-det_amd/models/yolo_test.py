@@ -254,7 +254,7 @@ class Model(nn.Module):
         """Pickling (train.py:881-899 stores whole model objects) and deepcopy (ModelEMA): HIP stream handles stay behind."""
         state = dict(self.__dict__)
         state['_ir_streams'] = {}
-        for k in ('_side_streams', '_stats_fork', '_main_stream'):
+        for k in ('_side_streams', '_stats_fork', '_main_stream', '_grad_hooks', '_tail_hook'):
             state.pop(k, None)
         return state
 
@@ -376,6 +376,11 @@ class Model(nn.Module):
             return None
 
         twin_last = getattr(self, '_twin_last', {})
+        ghooks = getattr(self, '_grad_hooks', None) if grad else None          # TrainStep: optimizer parts launched from backward
+
+        def ghook(i, out):
+            if ghooks and i in ghooks and torch.is_tensor(out) and out.requires_grad:
+                out.register_hook(ghooks[i])
         for m in self.model:
             i = m.i
             if not grad and tw:                                    # inference: a pair's output lives until its last reader has run
@@ -408,6 +413,7 @@ class Model(nn.Module):
                     else:
                         out = m.twin(mj, tw[xin.leader])
                 if out is not None:
+                    ghook(i, out)
                     tw[i] = out
                     prev = Lane(i, 0)
                     y.append(prev if i in self.save else None)
@@ -491,6 +497,7 @@ class Model(nn.Module):
                 ev.record(st_)
                 done[i] = (ev, st_)
                 ctx.__exit__(None, None, None)
+            ghook(i, x)
             prev = x
             y.append(x if i in self.save else None)
         if lanes:

@@ -422,6 +422,37 @@ def test_early_optimizer_is_the_same_training():
     assert ts1.optimizer.updates == ts2.optimizer.updates == 4
 
 
+@pytest.mark.parametrize('kind', ['fourier', 'add'])
+def test_optimizer_parts_launched_from_backward_are_the_same_training(kind, monkeypatch):
+    """MMIDET_OPT_PARTS=3: the optimizer's records in three parts by the order their gradients complete in backward, every part
+    launched on the optimizer's stream from a tensor hook as soon as its gradients exist, the rest after backward -- the same
+    elementwise update on the same numbers: weights, EMA and momenta bit-identical to the one-launch optimizer, and the hooks fired."""
+    monkeypatch.setenv('MMIDET_OPT_PARTS', '3')
+    m1, ts1, cfg = make(kind)
+    monkeypatch.setenv('MMIDET_OPT_PARTS', '0')
+    m2, ts2, _ = make(kind)
+    assert len(ts1._part_hooks) == 2 and not ts2._part_hooks
+    launched = []
+    orig = ts1.optimizer.launch_parts
+    ts1.optimizer.launch_parts = lambda a, b, stream=None: (launched.append((a, b, stream is not None)), orig(a, b, stream))[1]
+    for i in range(4):
+        b = batch(cfg, 70 + i)
+        l1, _ = ts1.step(*b)
+        l2, _ = ts2.step(*b)
+        assert torch.equal(l1, l2), i
+    assert sum(1 for a, b_, early in launched if early) >= 4 and any(not early for _, _, early in launched), launched
+    torch.cuda.synchronize()
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    e1, e2 = ts1.ema.ema.state_dict(), ts2.ema.ema.state_dict()
+    for k in e1:
+        assert torch.equal(e1[k], e2[k]), 'ema ' + k
+    for p1, p2 in zip(ts1.optimizer._sgd_params, ts2.optimizer._sgd_params):
+        assert torch.equal(ts1.optimizer._bufs[p1], ts2.optimizer._bufs[p2])
+    assert ts1.optimizer.updates == ts2.optimizer.updates == 4 and ts1.ema.updates == 4
+
+
 @pytest.mark.parametrize('nside', [1, 2])
 def test_first_step_orders_the_shared_wgrad_tables_across_lanes(monkeypatch, nside):
     """The round-2 GPU fault (MMIDET_NSIDE=1): the twin backbone lanes share the per-geometry pixel tables of the wgrad loaders,
