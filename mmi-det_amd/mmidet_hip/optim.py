@@ -210,6 +210,10 @@ class FusedSGDEMA(torch.optim.Optimizer):
             sel = [c for c in self._chunks_host if rp[c[0]] == q]
             arr = np.array(sel, dtype=np.int32).reshape(-1, 2)
             self._parts.append((torch.from_numpy(arr).to(self.device) if len(sel) else None, len(sel)))
+        # one table upload per part and step: the staging ring must hold four STEPS of them, or the host blocks on the GPU
+        nbytes = self._recs_host.view(np.uint8).reshape(-1).size
+        self._recs_stage = _Staging(nbytes, self.device, depth=4 * nparts)
+        self._hyper_stage = _Staging(36, self.device, depth=8)
 
     def refresh_upto(self, upto):
         """Point the table at this step's gradients of the parts 0 .. upto (later parts keep the pointers they have: nobody reads
