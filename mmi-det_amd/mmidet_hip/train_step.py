@@ -108,7 +108,11 @@ class TrainStep:
         # Generalised (MMIDET_OPT_PARTS=n, n >= 2): the records in n parts by the order their gradients complete in backward
         # (head / neck and the P5 transformer first ... the stems and the CEM last); tensor hooks on the outputs of n - 1 layers
         # launch every part whose gradients are complete on the optimizer's own stream, next to the MFMA-bound rest of the backward.
-        self.opt_parts = int(os.environ.get('MMIDET_OPT_PARTS', '0'))
+        # Measured (round 4, three interleaved pairs, yolov5l B=16): n = 3 119.87 / 120.08 ms against 119.86 / 120.09 with the one launch --
+        # the optimizer streams 8 GB through HBM and the Infinity Cache, which the co-running GEMMs pay for by as much as the
+        # tail gets shorter (the same answer the two-part form gave in round 2).  Off by default; capped at 4 parts (n = 5 made
+        # the host the bottleneck, 180 ms per step, not pursued).
+        self.opt_parts = min(int(os.environ.get('MMIDET_OPT_PARTS', '0')), 4)
         self._parts_launched = 0
         self._part_hooks = {}
         if self.opt_parts >= 2 and self.fused and reducer is None and hasattr(model, 'model'):
