@@ -418,10 +418,17 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
     KCur ca, cb[NB];
     int k0cur = ks0 * BK;
     if constexpr (UNI) {
-      const int tap0 = k0cur / p.Kc;
-      u_c0 = k0cur - tap0 * p.Kc;
-      u_ti = tap0 / tp.ntw;
-      u_tj = tap0 - u_ti * tp.ntw;
+      if (p.kord) {   // channel-slab major (see IgemmP::kord): slab s = (channel slab s / ntaps, tap s % ntaps)
+        const int s0 = k0cur / BK, cs = s0 / ntaps, tap0 = s0 - cs * ntaps;
+        u_c0 = cs * BK;
+        u_ti = tap0 / tp.ntw;
+        u_tj = tap0 - u_ti * tp.ntw;
+      } else {
+        const int tap0 = k0cur / p.Kc;
+        u_c0 = k0cur - tap0 * p.Kc;
+        u_ti = tap0 / tp.ntw;
+        u_tj = tap0 - u_ti * tp.ntw;
+      }
     }
     if (VEC && !UNI) {
       ca.init(k0cur + kq, p.Kc, tp.ntw);
@@ -502,12 +509,22 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
         // Past the last slab the cursor stays where it is: the surplus prefetch of the last iteration then re-reads the last
         // slab (a scalar offset beyond the tap table would leave the buffer's range check, which covers the lane offset).
         if (k0cur < tp.Ktot) {
-          u_c0 += BK;
-          if (u_c0 >= p.Kc) {
-            u_c0 = 0;
+          if (p.kord) {          // next tap of the same channel slab; after the last tap the next channel slab
             if (++u_tj == tp.ntw) {
               u_tj = 0;
-              ++u_ti;
+              if (++u_ti == u_nth) {
+                u_ti = 0;
+                u_c0 += BK;
+              }
+            }
+          } else {
+            u_c0 += BK;
+            if (u_c0 >= p.Kc) {
+              u_c0 = 0;
+              if (++u_tj == tp.ntw) {
+                u_tj = 0;
+                ++u_ti;
+              }
             }
           }
         }
