@@ -124,11 +124,6 @@ int mmi_set_uniform_loaders(int on);
  * next slab prefetched into registers (three workgroups per CU).  Same arithmetic and summation order: results are bit-identical.
  * Initial value from MMIDET_PF2 (default: see DESIGN.md).  Returns the old value. */
 int mmi_set_deep_prefetch(int on);
-/* A/B switch: order of the K slabs of 3x3 layers under the uniform-tap loaders.  0 = tap major (the general loaders' order: results
- * bit-identical to them), 1 = channel-slab major (the nine taps of one 32-channel slab back to back: the input window a workgroup
- * re-reads stays one slab deep in L2; same products, another summation order).  Initial value from MMIDET_KORDER.  Returns the old
- * value. */
-int mmi_set_k_order(int order);
 /* Tuning knob: force the forward/dgrad tile variant (128x128, 128x64 or 64x64; one workgroup per tile, stream-K off);
  * (0,0) restores the planner.  Used by tools/sweep_tiles.py to calibrate the planner's cost model. */
 int mmi_set_tile_override(int bm, int bn);

@@ -40,7 +40,6 @@ int g_uniform_loaders = getenv("MMIDET_UNIFORM_LOADERS") ? atoi(getenv("MMIDET_U
 int g_gemm_prec = 0;  // mmi_set_gemm_precision: 0 = exact fp32 MFMA, 1 = split-bf16 products for forward-layout GEMMs
 int g_tile_bm = 0, g_tile_bn = 0;  // mmi_set_tile_override (tuning): force one tile variant, one workgroup per tile
 int g_wgrad_force[3] = {0, 0, 0};  // mmi_set_wgrad_override (tuning): bm, bn, splits (0 = automatic)
-int g_kord = getenv("MMIDET_KORDER") ? atoi(getenv("MMIDET_KORDER")) : 0;   // mmi_set_k_order (A/B switch)
 int g_pf2 = getenv("MMIDET_PF2") ? atoi(getenv("MMIDET_PF2")) : 0;   // mmi_set_deep_prefetch (A/B switch)
 int g_sk_slots = 0;  // mmi_set_streamk_slots: 0 = chip-sized, > 0 = this many workgroups, < 0 = schedule off
 
@@ -228,12 +227,6 @@ extern "C" size_t mmi_workspace_header_bytes(int kind) {
     case 4: return (size_t)MMI_STAT_MAX_COUNTERS * sizeof(int);   // BatchNorm backward (mmi_bn_act_bwd*)
     default: return 0;
   }
-}
-
-extern "C" int mmi_set_k_order(int order) {
-  const int old = g_kord;
-  g_kord = order ? 1 : 0;
-  return old;
 }
 
 extern "C" int mmi_set_deep_prefetch(int on) {

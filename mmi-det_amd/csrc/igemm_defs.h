@@ -60,11 +60,6 @@ struct IgemmP {
   int bn_nnbt;
   float bn_eps, bn_momentum;
   double bn_inv_rows, bn_unbias;  // 1 / rows, rows / (rows - 1)
-  // Order of the K slabs of a 3x3 layer under the uniform-tap loaders: 0 = tap major (all channel slabs of tap 0, then tap 1 ...: the
-  // order of the general loaders), 1 = channel-slab major (the nine taps of channels 0..31, then of 32..63 ...): a workgroup's
-  // loads of one channel slab re-touch the same cache lines of its three-row input window nine times in a row, so the window it
-  // must keep in its XCD's L2 while it is being re-read is one slab deep (1/4 at 128 channels, 1/16 at 512) instead of all channels.
-  int kord;
   // pre-split operands (igemm_kernel<..., T8>, t8.hip): the T8 images of A and / or B (same element indexing, 6 bytes per element)
   const void* A8;
   const void* B8;
@@ -176,7 +171,6 @@ int launch_igemm_t8(const IgemmP& p, const IgemmDelta& q, const FwdPlan& f, dim3
 // the deep-prefetch variants (igemm_kernel<..., PF2>), instantiated in igemm_fwd_pf2.hip / igemm_dgrad_pf2.hip
 template <bool DGRAD>
 int launch_igemm_pf2(const IgemmP& p, const IgemmDelta& q, const FwdPlan& f, dim3 grid, int t8, hipStream_t s);
-extern int g_kord;  // mmi_set_k_order / MMIDET_KORDER: K-slab order of the uniform-tap loaders (IgemmP::kord)
 extern int g_pf2;   // mmi_set_deep_prefetch / MMIDET_PF2: 1 = take the deep-prefetch variants where they exist
 // T8 images announced for the next GEMM launch of this thread (mmi_gemm_operands_t8): [0] = A, [1] = B, [2], [3] = the twin problem's
 const void** t8_pending();

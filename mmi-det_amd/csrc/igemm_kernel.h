@@ -193,6 +193,18 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // 10 VALU instructions per K slab instead of 90-160: tools/mfma_mix.hip shows that VALU instructions issued next to an MFMA
 // stream cost MFMA throughput at three waves per SIMD (1 per MFMA: 87 % of peak, 2: 80 %, LDS reads: nothing), which is
 // exactly where the cursor-based loaders (1.4-2.9 VALU per MFMA, a third of them 64-bit) had left these kernels.
+// Order of the K slabs of a 3x3 layer under the uniform-tap loaders: MMI_KORD = 1 (default) = channel-slab major -- the nine taps
+// of channels 0..31, then of 32..63, ... -- instead of tap major (all channel slabs of tap 0, then tap 1, ...: the general loaders'
+// order, MMI_KORD = 0).  A workgroup's loads of one channel slab re-touch the same cache lines of its three-row input window nine
+// times in a row, so what its XCD's L2 must hold while the window is being re-read is one slab deep (1/4 of the window at 128
+// channels, 1/16 at 512) and not all channels.  Stand-alone, forward +5..8 % on every 3x3 layer (64 channels at 160x160: +24 %),
+// stride-1 dgrad +3 %, the stride-2 parity classes -5 % (six launches per step); in the step -1.2 % on a box whose memory side is
+// slow (133.6 -> 132.0 ms) and -0.2 % on a fast one (118.58 -> 118.36): profiles/r04_k_order_ab.txt.  Same products, another
+// summation order than the general loaders (which these loaders used to equal bit for bit); 1x1 layers have one tap and do not
+// change.  A compile-time constant (an A/B build sets -DMMI_KORD=0: tools/ab/).
+#ifndef MMI_KORD
+#define MMI_KORD 1
+#endif
 #ifndef MMI_UNI_OCC
 #define MMI_UNI_OCC 3
 #endif
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
     KCur ca, cb[NB];
     int k0cur = ks0 * BK;
     if constexpr (UNI) {
-      if (p.kord) {   // channel-slab major (see IgemmP::kord): slab s = (channel slab s / ntaps, tap s % ntaps)
+      if (MMI_KORD) {   // channel-slab major: slab s = (channel slab s / ntaps, tap s % ntaps)
         const int s0 = k0cur / BK, cs = s0 / ntaps, tap0 = s0 - cs * ntaps;
         u_c0 = cs * BK;
         u_ti = tap0 / tp.ntw;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
         // Past the last slab the cursor stays where it is: the surplus prefetch of the last iteration then re-reads the last
         // slab (a scalar offset beyond the tap table would leave the buffer's range check, which covers the lane offset).
         if (k0cur < tp.Ktot) {
-          if (p.kord) {          // next tap of the same channel slab; after the last tap the next channel slab
+          if (MMI_KORD) {        // next tap of the same channel slab; after the last tap the next channel slab
             if (++u_tj == tp.ntw) {
               u_tj = 0;
               if (++u_ti == u_nth) {

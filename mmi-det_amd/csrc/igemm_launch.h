@@ -70,7 +70,6 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     const int64_t b_bytes = DGRAD ? (int64_t)p.Kc * p.ldb * 4 : (int64_t)p.Ncol * p.ldb * 4;
     if (a_bytes < (1LL << 31) && b_bytes < (1LL << 31)) {
       uni = true;
-      p.kord = (g_kord && p.KH * p.KW > 1 && !p.par) ? 1 : 0;   // (parity classes of a stride-2 dgrad have 1-4 taps: measured slower)
       p.a_bytes = (uint32_t)a_bytes;
       p.b_bytes = (uint32_t)b_bytes;
       const int64_t c_bytes = ((int64_t)(p.M - 1) * p.ldc + p.Ncol) * 4;

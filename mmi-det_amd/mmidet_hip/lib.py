@@ -67,7 +67,6 @@ _SIGS = {
     'mmi_set_gemm_precision': (c_int, [c_int]),
     'mmi_set_uniform_loaders': (c_int, [c_int]),
     'mmi_set_deep_prefetch': (c_int, [c_int]),
-    'mmi_set_k_order': (c_int, [c_int]),
     'mmi_conv_fwd_workspace': (c_size_t, [POINTER(ConvDesc)]),
     'mmi_conv_fwd': (c_int, [P, P, P, P, P, P, c_size_t, POINTER(ConvDesc), P]),
     'mmi_conv_bn_fwd': (c_int, [P, P, P, P, POINTER(BnStats), P, c_size_t, POINTER(ConvDesc), P]),
@@ -185,7 +184,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_set_k_order', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

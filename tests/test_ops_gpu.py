@@ -278,9 +278,11 @@ def test_build_targets_bit_exact(tag, bs, per):
 @pytest.mark.parametrize('mode', [0, 2, 3], ids=['fp32', 'bf16x6', 'bf16x9'])
 def test_uniform_loaders_are_bit_identical_to_the_general_ones(case, mode):
     """mmi_set_uniform_loaders: the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders only change how a tile's
-    addresses are formed; the arithmetic and its order are those of the general cursor-based loaders, so y, dx and dw must be
-    equal bit for bit -- including zero padding at the borders, ragged tiles and the stride-2 parity classes.  Both arithmetics
-    that have these loaders: the fp32 MFMA default and the six-product split (mmi_set_gemm_precision(2))."""
+    addresses are formed: for 1x1 layers and for every weight gradient the arithmetic and its order are those of the general
+    cursor-based loaders -- y, dx, dw, statistics equal bit for bit.  For 3x3 layers the uniform-tap loaders walk the K slabs
+    channel-slab major since round 4 (csrc/igemm_kernel.h: MMI_KORD; the general ones tap major): the same products in another
+    summation order, so forward and dgrad agree to what two fp32 summation orders differ by -- including zero padding at the
+    borders, ragged tiles and the stride-2 parity classes.  All arithmetics that have these loaders."""
     from mmidet_hip import lib, ops
     lib.set_gemm_precision(mode)
     N, H, W, Ci, Co, k, s = case
@@ -308,4 +310,7 @@ def test_uniform_loaders_are_bit_identical_to_the_general_ones(case, mode):
         lib.set_uniform_loaders(1)
         lib.set_gemm_precision(0)
     for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dw', 'BN statistics partials')):
-        assert torch.equal(a, b), what
+        if k == 1 or what == 'dw':
+            assert torch.equal(a, b), what
+        else:
+            close(a, b, tol=3e-6, what=what + ' (channel-slab major vs tap major K order)')

@@ -153,41 +153,3 @@ def test_deep_prefetch_k_loop_is_bit_identical(shape, mode):
     for name, a, b in zip(('y', 'dx', 'BN partials'), base, deep):
         n = a.numel() if name != 'BN partials' else lib.conv_fwd_row_blocks(desc) * 2 * Cout
         assert torch.equal(a.reshape(-1)[:n], b.reshape(-1)[:n]), name
-
-
-@pytest.mark.parametrize('mode', [0, 3], ids=['fp32', 'bf16x9'])
-@pytest.mark.parametrize('shape', SHAPES)
-def test_channel_slab_major_k_order_is_the_same_convolution(shape, mode):
-    """mmi_set_k_order(1): the nine taps of one 32-channel slab back to back instead of all channel slabs of one tap -- the same
-    products in another summation order (forward and data gradient, stream-K segments and parity classes included)."""
-    from mmidet_hip import alloc, lib, ops
-    from test_ops_gpu import close
-    N, H, W, Cin, Cout, k, s = shape
-    d = dev()
-    st = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator().manual_seed(8)
-    x = torch.randn(N, H, W, Cin, generator=g).to(d)
-    w = (torch.randn(Cout, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).to(d)
-    desc = ops._desc((N, H, W, Cin), Cout, k, s, Cin, Cout)
-    dy = torch.randn(N, desc.Ho, desc.Wo, Cout, generator=g).to(d)
-
-    def run():
-        y = alloc.empty((N, desc.Ho, desc.Wo, Cout), dtype=torch.float32, device=d)
-        dx = alloc.empty_like(x)
-        ops.conv_fwd(x, w, None, y, None, desc, st)
-        ops.conv_dgrad(dy, w, dx, desc, st)
-        torch.cuda.synchronize()
-        return y, dx
-
-    lib.set_gemm_precision(mode)
-    try:
-        base = run()
-        lib.set_k_order(1)
-        other = run()
-    finally:
-        lib.set_k_order(0)
-        lib.set_gemm_precision(0)
-    for name, a, b in zip(('y', 'dx'), other, base):
-        close(a, b, tol=3e-6, what=name + ' (channel-slab major vs tap major)')
-        if k == 1:
-            assert torch.equal(a, b)          # a 1x1 layer has one tap: nothing changes

@@ -18,7 +18,7 @@ SHAPES = [(16, 160, 160, 64, 64, 3, 1), (16, 80, 80, 128, 128, 3, 1), (16, 40, 4
 def main():
     d = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
-    modes = [('fp32', 0, 0, 0), ('fp32/ko', 0, 0, 2), ('x9/ko', 3, 0, 2), ('x6/ko', 2, 0, 2), ('fp32/pf2', 0, 0, 1), ('x9', 3, 0, 0), ('x9/pf2', 3, 0, 1), ('x9+t8', 3, 3, 0), ('x9+t8/pf2', 3, 3, 1), ('x6', 2, 0, 0),
+    modes = [('fp32', 0, 0, 0), ('fp32/pf2', 0, 0, 1), ('x9', 3, 0, 0), ('x9/pf2', 3, 0, 1), ('x9+t8', 3, 3, 0), ('x9+t8/pf2', 3, 3, 1), ('x6', 2, 0, 0),
              ('x6/pf2', 2, 0, 1), ('x6+t8', 2, 3, 0), ('x6+t8/pf2', 2, 3, 1)]
     if os.environ.get('BENCH_MODES'):
         modes = [m for m in modes if m[0] in os.environ['BENCH_MODES'].split(',')]
@@ -40,8 +40,7 @@ def main():
         res = {'fwd': [], 'dgrad': [], 'wgrad': []}
         for name, prec, t8, pf2 in modes:
             lib.set_gemm_precision(prec)
-            lib.set_deep_prefetch(1 if pf2 == 1 else 0)
-            lib.set_k_order(1 if pf2 == 2 else 0)
+            lib.set_deep_prefetch(pf2)
             nb = lib.conv_wgrad_workspace(desc)
             ws = torch.zeros(max(nb // 4, 1), device=d)
             part = torch.empty(lib.conv_fwd_row_blocks(desc) * 2 * Co, device=d)
@@ -66,7 +65,6 @@ def main():
             res['wgrad'].append(fl / timeit(wgrad) / 1e9)
             lib.set_gemm_precision(0)
             lib.set_deep_prefetch(0)
-            lib.set_k_order(0)
         for dname, vals in res.items():
             print('%-32s %-6s' % (str((B, H, W, Ci, Co, k, s)), dname) + ''.join('%10.1f' % v for v in vals), flush=True)
 
