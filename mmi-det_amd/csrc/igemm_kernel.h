@@ -201,7 +201,7 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4 (&t)[NP]) {
 // stride-1 dgrad +3 %, the stride-2 parity classes -5 % (six launches per step); in the step -1.2 % on a box whose memory side is
 // slow (133.6 -> 132.0 ms) and -0.2 % on a fast one (118.58 -> 118.36): profiles/r04_k_order_ab.txt.  Same products, another
 // summation order than the general loaders (which these loaders used to equal bit for bit); 1x1 layers have one tap and do not
-// change.  A compile-time constant (an A/B build sets -DMMI_KORD=0: tools/ab/).
+// change.  A compile-time constant (an A/B build compiles the igemm_fwd* / igemm_dgrad* units with -DMMI_KORD=0 and is loaded through MMIDET_HIP_LIB).
 #ifndef MMI_KORD
 #define MMI_KORD 1
 #endif
