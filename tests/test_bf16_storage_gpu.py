@@ -283,7 +283,9 @@ def test_bf16_storage_loss_curve_tracks_fp32_over_300_steps():
                                   (1, 33, 17, 96, 64, 3, 1)])
 def test_bf16_storage_uniform_loaders_are_bit_identical_to_the_general_ones(case):
     """Round 3: the bf16-storage GEMMs (PREC = 4) take the uniform-tap (forward, dgrad) and pixel-table (wgrad) loaders with 2-byte
-    activation offsets; as for fp32 they only change how addresses are formed: y, dx (bf16) and dw (fp32) equal bit for bit."""
+    activation offsets; as for fp32 they only change how addresses are formed: dw (fp32), and y / dx (bf16) of 1x1 layers, equal
+    bit for bit; 3x3 forward / dgrad walk the K slabs channel-slab major since round 4 (another fp32 summation order before the
+    bf16 rounding of the result: equal to one bf16 ulp in a few elements)."""
     from mmidet_hip import lib, ops
     N, H, W, Ci, Co, k, s = case
     d = dev()
@@ -310,7 +312,12 @@ def test_bf16_storage_uniform_loaders_are_bit_identical_to_the_general_ones(case
     finally:
         lib.set_uniform_loaders(1)
     for a, b, what in zip(outs[0], outs[1], ('y', 'dx', 'dw')):
-        assert torch.equal(a, b), what
+        if k == 1 or what == 'dw':
+            assert torch.equal(a, b), what
+        else:
+            diff = (a.float() - b.float()).abs()
+            assert float(diff.max()) <= 2.0 ** -7 * float(b.float().abs().max()), what          # one bf16 ulp of the largest value
+            assert float((diff > 0).float().mean()) < 0.02, what                                # and only where a rounding tie flipped
     # and the numbers are those of fp32 torch on the same bf16-rounded operands
     yr = F.conv2d(nchw(x.float().cpu()), nchw(w.cpu()), None, s, k // 2)
     close(nchw(outs[0][0].float()), yr, tol=1e-2, what='y vs torch')
