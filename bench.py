@@ -548,7 +548,7 @@ def main():
         # lane's BatchNorm passes (yolov5x at 1280: ~1 %).  Probed like the launch mode, but only where the GPU is the bound
         # (a host-bound step's timing jitters by more than the forms differ, and twin launches halve the host's work), and a
         # switch needs a 1.5 % margin.
-        if (getattr(model, 'twin', False) and args.storage == 'f32' and enq < 0.8 * ms
+        if (getattr(model, 'twin', False) and args.storage == 'f32' and enq < 0.8 * ms and not ddp      # (one GPU only: the N > 1 path keeps twin launches)
                 and os.environ.get('MMIDET_FORM_PROBE', '1') != '0'):
             model.twin = False
             ts.step(imgs, tg)                              # first lane-form step: its streams, workspaces and pixel tables
