@@ -18,20 +18,36 @@ def build(force=False, verbose=True):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
     hdr_m = max(os.path.getmtime(p) for p in deps if not p.endswith('.hip'))
-    procs = []
+    todo = []
     for s in srcs:
         o = s[:-4] + '.o'
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_m):
             continue
-        cmd = ['hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-c', s, '-o', o] + \
-            FLAGS.get(os.path.basename(s), [])
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+        todo.append(['hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-c', s, '-o', o] + FLAGS.get(os.path.basename(s), []))
+    # at most MAXJ compilers at once (a hipcc of one of the kernel-template units takes 1-2 GB; the build box has 8 cores / 64 GB);
+    # the heaviest units (the implicit-GEMM instantiations) go first so that they overlap with everything else
+    todo.sort(key=lambda c: -os.path.getsize(c[c.index('-c') + 1]) - (1 << 30) * ('igemm' in os.path.basename(c[c.index('-c') + 1])))
+    maxj = int(os.environ.get('MMIDET_BUILD_JOBS', '12'))
+    running = []
+    while todo or running:
+        while todo and len(running) < maxj:
+            cmd = todo.pop(0)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        for item in list(running):
+            rc = item[1].poll()
+            if rc is None:
+                continue
+            running.remove(item)
+            if rc != 0:
+                for _, p in running:
+                    p.kill()
+                raise RuntimeError('hipcc failed: ' + ' '.join(item[0]))
+        if running:
+            import time
+            time.sleep(0.2)
     cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
