@@ -332,10 +332,16 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
     float* y2; float* t; float* chansum; float* y3; float* stat_part; int ldx, H, W;
   } p{px, pw2, pmi2, pg2, pb2, pfactor, psbias, pw3, out.y2, out.t, out.chansum, out.y3, out.stat_part, ldx, H_, W_};
   constexpr int XS = TS + 6, RS = TS + 4, TT = TS + 2;       // 22, 20, 18
+  // Record pitch of a position's 24 channels in LDS: 28 floats.  At 24 (96 B) the 16-byte reads of the stencil and conv3 phases
+  // fell on 8 of the 16 bank groups and the scalar stores of the conv2 phase on 8 of the 64 banks -- 97 M of the kernel's 172 M
+  // LDS cycles were bank conflicts (round 4, profiles/r04_pmc_cem_module.txt); 112 B = 7 bank groups makes the vector reads
+  // conflict-free and halves the stores' pile-up.  The room comes from the stencil phase, which now writes t IN PLACE over r (t at a
+  // position needs r at that position and the channel sums of its neighbours, which live in cs): no separate t tile, 52 KB of LDS
+  // instead of 77, three workgroups per CU instead of two.
+  constexpr int RP = 28;
   __shared__ float xs[XS * XS * 3];
-  __shared__ __align__(16) float rs[RS * RS * 24];
+  __shared__ __align__(16) float rs[RS * RS * RP];
   __shared__ float cs[RS * RS];
-  __shared__ __align__(16) float ts[TT * TT * 24];
   __shared__ float red[2][4][3];
   const int t = threadIdx.x, n = blockIdx.z;
   const int h0 = blockIdx.y * TS, w0 = blockIdx.x * TS;
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
           const float z = (acc[k][h] - m) * is * g + be;
           v[k][h] = in[h] ? (z > 0.f ? z : 0.1f * z) : 0.f;
         }
-        rs[qq[0] * 24 + o0 + k] = v[k][0];
-        rs[qq[1] * 24 + o0 + k] = v[k][1];
+        rs[qq[0] * RP + o0 + k] = v[k][0];
+        rs[qq[1] * RP + o0 + k] = v[k][1];
       }
       if (p.y2 != nullptr) {
 #pragma unroll
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 9; ++k) nb[k] = cs[(i + k / 3) * RS + j + k % 3];
     stencils8(nb, st);
-    const float* rsrc = rs + ((i + 1) * RS + j + 1) * 24;
+    float* rsrc = rs + ((i + 1) * RS + j + 1) * RP;      // r of this position in, t of this position out
     const bool interior = in && i >= 1 && i < TT - 1 && j >= 1 && j < TT - 1;
     float* dst = (interior && p.t != nullptr) ? p.t + (((int64_t)n * H + ih) * W + iw) * 24 : nullptr;
 #pragma unroll
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
       f32x4 v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = in ? rv[k] + p.factor[o + k] * st[(o + k) & 7] + p.sbias[o + k] : 0.f;
-      *reinterpret_cast<f32x4*>(ts + q * 24 + o) = v;
+      *reinterpret_cast<f32x4*>(rsrc + o) = v;
       if (dst != nullptr) *reinterpret_cast<f32x4*>(dst + o) = v;
     }
   }
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
   f32x2 a2[3] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll 1          // (fully unrolled, the 54 ds_read_b128 of the nine taps are all issued up front: 216 VGPRs)
   for (int tap = 0; tap < 9; ++tap) {
-    const float* src = ts + ((ti + tap / 3) * TT + tj + tap % 3) * 24;
+    const float* src = rs + ((ti + 1 + tap / 3) * RS + tj + 1 + tap % 3) * RP;      // t on the 18x18 interior of the 20x20 grid
 #pragma unroll
     for (int c = 0; c < 24; c += 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
