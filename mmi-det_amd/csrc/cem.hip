@@ -320,8 +320,8 @@ struct CemOut {
   float* y3;
   float* stat_part;
 };
-template <int OB>
-__global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restrict__ px, const float* __restrict__ pw2,
+template <int OB, bool Y2S, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void cem_fused_fwd_kernel(const float* __restrict__ px, const float* __restrict__ pw2,
                                                             const float* __restrict__ pmi2, const float* __restrict__ pg2,
                                                             const float* __restrict__ pb2, const float* __restrict__ pfactor,
                                                             const float* __restrict__ psbias, const float* __restrict__ pw3,
@@ -342,13 +342,29 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
   __shared__ float xs[XS * XS * 3];
   __shared__ __align__(16) float rs[RS * RS * RP];
   __shared__ float cs[RS * RS];
+  // y2 (conv2's raw output, kept for the backward) goes to HBM through LDS: a thread of the conv2 phase owns two positions and
+  // produces their channels two at a time, so storing from its registers meant 24 dword stores per position whose 64 lanes hit 64
+  // different cache lines -- 5.4 M store instructions per launch, each a lane-by-lane pass through the memory pipe, about half of
+  // the kernel's time.  From the tile in LDS the same bytes leave as 16-byte lane accesses over contiguous 1.5 KB runs.
+  // (Y2S = false, OB = 4 only: a position's four channels of an iteration leave as one 16-byte store from registers -- a
+  //  quarter of the LDS form's instructions again at stride 96 B, but no 24 KB tile: three workgroups per CU)
+  static_assert(Y2S || OB == 4, "direct y2 stores need four channels per iteration");
+  __shared__ __align__(16) float y2s[Y2S ? TS * TS * 24 : 4];
   __shared__ float red[2][4][3];
   const int t = threadIdx.x, n = blockIdx.z;
   const int h0 = blockIdx.y * TS, w0 = blockIdx.x * TS;
   const int H = p.H, W = p.W;
-  for (int e = t; e < XS * XS * 3; e += 256) {
-    const int c = e % 3, q = e / 3, ih = h0 - 3 + q / XS, iw = w0 - 3 + q % XS;
-    xs[e] = (ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
+  {      // (all six loads of a thread in flight at once: as a rolled loop each waited for its own HBM round trip)
+    constexpr int NX = (XS * XS * 3 + 255) / 256;
+    float xv[NX];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int e = t + u * 256, c = e % 3, q = e / 3, ih = h0 - 3 + q / XS, iw = w0 - 3 + q % XS;
+      xv[u] = (e < XS * XS * 3 && ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u)
+      if (t + u * 256 < XS * XS * 3) xs[t + u * 256] = xv[u];
   }
   __syncthreads();
   // ---- r = LeakyReLU(BN2(conv2(x))) on the 20x20 region; zero outside the image.  A thread owns TWO positions (q, q + 200)
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
   // SGPR broadcast to both halves, i.e. twice the fp32 VALU rate of the scalar form, and the 648 weights are fetched once
   // for two pixels.  Per-position sums keep the tap-major / channel-minor order of smallconv_kernel<3, 24>.
   if (t < RS * RS / 2) {
-    int qq[2];
+    int qq[2], ypos[2];
     bool in[2], interior[2];
     f32x2 xin[27];                       // the two positions' 3x3x3 input patches, position h in half h
     {
@@ -367,6 +383,7 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
         const int i = qq[h] / RS, j = qq[h] % RS, ih = h0 - 2 + i, iw = w0 - 2 + j;
         in[h] = ih >= 0 && iw >= 0 && ih < H && iw < W;
         interior[h] = in[h] && i >= 2 && i < RS - 2 && j >= 2 && j < RS - 2;
+        ypos[h] = (i - 2) * TS + (j - 2);      // (only used where interior)
         sp[h] = xs + (i * XS + j) * 3;
       }
 #pragma unroll
@@ -408,10 +425,15 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
         rs[qq[1] * RP + o0 + k] = v[k][1];
       }
       if (p.y2 != nullptr) {
+        if constexpr (Y2S) {
 #pragma unroll
-        for (int k = 0; k < OB; ++k) {
-          if (interior[0]) p.y2[pix0 * 24 + o0 + k] = acc[k][0];
-          if (interior[1]) p.y2[pix1 * 24 + o0 + k] = acc[k][1];
+          for (int k = 0; k < OB; ++k) {
+            if (interior[0]) y2s[ypos[0] * 24 + o0 + k] = acc[k][0];
+            if (interior[1]) y2s[ypos[1] * 24 + o0 + k] = acc[k][1];
+          }
+        } else {
+          if (interior[0]) *reinterpret_cast<f32x4*>(p.y2 + pix0 * 24 + o0) = f32x4{acc[0][0], acc[1 % OB][0], acc[2 % OB][0], acc[3 % OB][0]};
+          if (interior[1]) *reinterpret_cast<f32x4*>(p.y2 + pix1 * 24 + o0) = f32x4{acc[0][1], acc[1 % OB][1], acc[2 % OB][1], acc[3 % OB][1]};
         }
       }
       // channel sum with the grouping of chansum_kernel: ((c0 + c1) + (c2 + c3)) per group of four, groups added in order
@@ -430,6 +452,14 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
     }
   }
   __syncthreads();
+  if (Y2S && p.y2 != nullptr) {
+#pragma unroll
+    for (int e = t; e < TS * TS * 6; e += 256) {
+      const int pos = e / 6, g4 = (e - pos * 6) * 4, ih = h0 + pos / TS, iw = w0 + pos % TS;
+      if (ih < H && iw < W)
+        *reinterpret_cast<f32x4*>(p.y2 + (((int64_t)n * H + ih) * W + iw) * 24 + g4) = *reinterpret_cast<const f32x4*>(y2s + pos * 24 + g4);
+    }
+  }
   // ---- t = r + factor * stencil(chansum) + bias on the 18x18 region; zero outside the image
 #pragma unroll 1
   for (int q = t; q < TT * TT; q += 256) {
@@ -441,8 +471,6 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
     for (int k = 0; k < 9; ++k) nb[k] = cs[(i + k / 3) * RS + j + k % 3];
     stencils8(nb, st);
     float* rsrc = rs + ((i + 1) * RS + j + 1) * RP;      // r of this position in, t of this position out
-    const bool interior = in && i >= 1 && i < TT - 1 && j >= 1 && j < TT - 1;
-    float* dst = (interior && p.t != nullptr) ? p.t + (((int64_t)n * H + ih) * W + iw) * 24 : nullptr;
 #pragma unroll
     for (int o = 0; o < 24; o += 4) {
       const f32x4 rv = *reinterpret_cast<const f32x4*>(rsrc + o);
@@ -450,10 +478,18 @@ __global__ __launch_bounds__(256) void cem_fused_fwd_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = in ? rv[k] + p.factor[o + k] * st[(o + k) & 7] + p.sbias[o + k] : 0.f;
       *reinterpret_cast<f32x4*>(rsrc + o) = v;
-      if (dst != nullptr) *reinterpret_cast<f32x4*>(dst + o) = v;
     }
   }
   __syncthreads();
+  if (p.t != nullptr) {      // t of the tile's own 16x16 positions, for the backward: coalesced, as y2 above
+#pragma unroll
+    for (int e = t; e < TS * TS * 6; e += 256) {
+      const int pos = e / 6, g4 = (e - pos * 6) * 4, pi = pos / TS, pj = pos % TS, ih = h0 + pi, iw = w0 + pj;
+      if (ih < H && iw < W)
+        *reinterpret_cast<f32x4*>(p.t + (((int64_t)n * H + ih) * W + iw) * 24 + g4) =
+            *reinterpret_cast<const f32x4*>(rs + ((pi + 2) * RS + pj + 2) * RP + g4);
+    }
+  }
   // ---- y3 = conv3(t) on the 16x16 tile (tap-major, channel-minor: the order of smallconv_kernel<24,3>)
   const int ti = t >> 4, tj = t & 15, oh = h0 + ti, ow = w0 + tj;
   const bool live = oh < H && ow < W;
@@ -906,16 +942,23 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
   MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0 && ((uintptr_t)t & 15) == 0, "mmi_cem_fused_fwd: y2 / t must be 16-byte aligned");
   const CemOut out{y2, t, chansum, y3, stat_partials3};
   const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
-  static const int ob = [] {      // output channels of conv2 per scalar-weight fetch (A/B switch: 2 and 3 measure alike -- 1.06 ms
-    const char* e = getenv("MMIDET_CEM_OB");   // at 16 x 640 x 640 -- and 4, which spills SGPRs, 1.09; 4 keeps chansum's grouping)
+  static const int ob = [] {      // output channels of conv2 per scalar-weight fetch (A/B switch)
+    const char* e = getenv("MMIDET_CEM_OB");
     const int v = e ? atoi(e) : 2;
     return (v == 2 || v == 3 || v == 4) ? v : 2;
   }();
-#define CEM_LAUNCH(OB_) hipLaunchKernelGGL(cem_fused_fwd_kernel<OB_>, grid, dim3(256), 0, (hipStream_t)stream, x, w2, mean_invstd2, gamma2, \
-                                           beta2, factor, sobel_bias, w3, out, ldx, H, W)
-  if (ob == 2) CEM_LAUNCH(2);
-  else if (ob == 3) CEM_LAUNCH(3);
-  else CEM_LAUNCH(4);
+  // 1 (default): OB = 4, y2 from registers, 3 workgroups per CU; 0: y2 staged through LDS, 2 workgroups per CU.  At 16 x 640 x 640
+  // (profiles/r04_cem_forward_forms.txt): eval forward 0.71 vs 0.80-0.93 ms, training forward 1.09 vs 1.21-1.34, module 2.97 vs 3.08-3.19
+  static const int form = [] {
+    const char* e = getenv("MMIDET_CEM_FORM");
+    return e ? atoi(e) : 1;
+  }();
+#define CEM_LAUNCH(OB_, Y2S_, WPE_) hipLaunchKernelGGL((cem_fused_fwd_kernel<OB_, Y2S_, WPE_>), grid, dim3(256), 0, (hipStream_t)stream, x, w2, \
+                                           mean_invstd2, gamma2, beta2, factor, sobel_bias, w3, out, ldx, H, W)
+  if (form == 1) CEM_LAUNCH(4, false, 3);
+  else if (ob == 2) CEM_LAUNCH(2, true, 2);
+  else if (ob == 3) CEM_LAUNCH(3, true, 2);
+  else CEM_LAUNCH(4, true, 2);
 #undef CEM_LAUNCH
   MMI_CHECK_LAUNCH("mmi_cem_fused_fwd");
   return MMI_OK;

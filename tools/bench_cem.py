@@ -44,15 +44,25 @@ def fwd_bwd():
     ops.join_pending()
 
 
+def fwd_train():
+    y = m(x)
+    ops.join_pending()
+    return y
+
+
 px = B * H * W
-for fused, bwd, bn in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+rows = ((False, False, False), (True, False, False), (True, True, False), (True, True, True))
+if os.environ.get('BENCH_CEM_FUSED_ONLY') == '1':
+    rows = rows[-1:]
+for fused, bwd, bn in rows:
     ops.CEM_FUSED, ops.CEM_BWD_FUSED, ops.CEM_BWD_BN = fused, bwd, bn
     m.train()
     t_tr = timed(fwd_bwd)
+    t_tf = timed(fwd_train)
     m.eval()
     t_ev = timed(fwd)
     m.train()
-    print('fused forward=%d  fused backward middle=%d  + BN2 reduction=%d  train fwd+bwd %.3f ms   eval fwd %.3f ms' % (fused, bwd, bn, t_tr, t_ev))
+    print('fused forward=%d  fused backward middle=%d  + BN2 reduction=%d  train fwd+bwd %.3f ms   train fwd %.3f ms   eval fwd %.3f ms' % (fused, bwd, bn, t_tr, t_tf, t_ev))
 # algorithmic bytes of the fused training forward: x twice (pre-pass + main) + y2, t (24 ch) + chansum + y3 written, then BN3+act: y3, x read, out written
 fw = px * 4 * (3 + 3 + 24 + 24 + 1 + 3 + 3 + 3 + 3)
 print('fused training forward, algorithmic HBM bytes: %.1f MB (%.3f ms at 8 TB/s)' % (fw / 1e6, fw / 8e12 * 1e3))
