@@ -215,7 +215,9 @@ int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, co
  * fold launch in between; fixed fold order, fp64).  dout may come in two tensors split at channel `split` (gradient of the
  * two outputs of mmi_bn_act_fwd_split), dgamma/dbeta then go to two parameter pairs; split = C: one of each (the *1
  * arguments may be NULL).  Workspace: mmi_bn_act_bwd_workspace(rows, C) bytes, 16-byte aligned, zero-filled when first
- * handed over (arrival counters at its head; self-cleaning; launches sharing it must be ordered on one stream). */
+ * handed over (arrival counters at its head; self-cleaning; launches sharing it must be ordered on one stream).
+ * dy = NULL: the sums only (dgamma / dbeta are finished when the call's launches are); the apply pass is then the caller's, on
+ * its own way into a consumer (mmi_cem_conv2_wgrad_bn). */
 size_t mmi_bn_act_bwd_workspace(int64_t rows, int C);
 int mmi_bn_act_bwd(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, int split,
                    const float* mean_invstd, const float* gamma, const float* beta, void* workspace, size_t workspace_bytes,
@@ -467,6 +469,22 @@ int mmi_cem_bwd_mid(const float* dy3, const float* w3, const float* chansum, con
                     const float* beta2, float* bn_partials, int N, int H, int W, void* stream);
 int mmi_cem_blocks(int N, int H, int W);
 int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_partials, int N, int H, int W, void* stream);
+/* Training forward in two launches (round 4; conv2 is evaluated once instead of 2.56 times per pixel): y2 = conv2(x) stored, with
+ * BN2's statistics partials [mmi_cem_conv2_fwd_blocks][2][24] -> mmi_bn_finalize; then y2 -> r -> t -> y3 (mmi_cem_fwd_from_y2:
+ * the fused kernel reading y2 instead of recomputing it; t / chansum written when non-NULL, y3 statistics partials
+ * [mmi_cem_blocks][2][3]).  Results are bit-identical to mmi_cem_conv2_stats + mmi_cem_fused_fwd. */
+/* conv2's weight gradient with BatchNorm2 + LeakyReLU's backward applied in the loader (the image takes no gradient, so dy2 has no
+ * other reader): dw2 = wgrad(x, dy2(dr, y2)), dy2 never in HBM.  dgamma2 / dbeta2: finished by mmi_bn_act_bwd(..., dy = NULL, ...)
+ * earlier on the same stream.  Workspace: mmi_cem_conv2_wgrad_bn_workspace bytes (plain scratch, no counters). */
+size_t mmi_cem_conv2_wgrad_bn_workspace(int N, int H, int W);
+int mmi_cem_conv2_wgrad_bn(const float* dr, const float* y2, const float* x, int ldx, const float* mean_invstd2, const float* gamma2,
+                           const float* beta2, const float* dgamma2, const float* dbeta2, int frozen, float* dw2, void* workspace,
+                           size_t workspace_bytes, int N, int H, int W, void* stream);
+int mmi_cem_conv2_fwd_blocks(int N, int H, int W);
+int mmi_cem_conv2_fwd(const float* x, int ldx, const float* w2, float* y2, float* stat_partials, int N, int H, int W, void* stream);
+int mmi_cem_fwd_from_y2(const float* y2, const float* mean_invstd2, const float* gamma2, const float* beta2, const float* factor,
+                        const float* sobel_bias, const float* w3, float* t, float* chansum, float* y3, float* stat_partials3, int N,
+                        int H, int W, void* stream);
 int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const float* mean_invstd2, const float* gamma2, const float* beta2,
                       const float* factor, const float* sobel_bias, const float* w3, float* y2, float* t, float* chansum, float* y3,
                       float* stat_partials3, int N, int H, int W, void* stream);

@@ -654,7 +654,7 @@ template <typename T>
 int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1, int ldd1, const float* mean_invstd,
                     const mmi_bn_map& mp, void* workspace, size_t workspace_bytes, T* dy, int lddy, int64_t rows, int C, int act,
                     int frozen, void* stream) {
-  MMI_CHECK_ARG(y && dout && mean_invstd && workspace && dy && rows > 0 && C > 0, "mmi_bn_act_bwd: bad arguments");
+  MMI_CHECK_ARG(y && dout && mean_invstd && workspace && rows > 0 && C > 0, "mmi_bn_act_bwd: bad arguments");   // (dy == NULL: sums only)
   if (int e = check_map(mp, C, true, "mmi_bn_act_bwd")) return e;
   const bool two = map_two(mp);
   MMI_CHECK_ARG(!two || (dout1 != nullptr && C > 8), "mmi_bn_act_bwd: the channel map needs a second gradient tensor");
@@ -683,6 +683,7 @@ int bn_act_bwd_impl(const T* y, int ldy, const T* dout, int ldd, const T* dout1,
                          partials, rows, C, act, rpp, f);
     MMI_CHECK_LAUNCH("mmi_bn_act_bwd(reduce)");
   }
+  if (dy == nullptr) return MMI_OK;      // the caller applies on its own way in (mmi_cem_conv2_wgrad_bn)
   return launch_apply<T>(y, ldy, dout, ldd, dout1, ldd1, mean_invstd, mp, dy, lddy, rows, C, act, frozen, s);
 }
 }  // namespace

@@ -90,18 +90,33 @@ __global__ __launch_bounds__(256) void smallconv_kernel(const float* __restrict_
 // Round 2: the next tile's operands are fetched into registers while the current tile is being multiplied (the wide operand
 // with 16-byte loads when VEC), and the three narrow channels of a pixel cost two VALU instructions -- one packed FMA
 // (v_pk_fma_f32, the wide value broadcast to both halves) + one FMA -- instead of three.
-template <int CIN, int COUT, bool VEC>
+// BNF (conv2 of the CEM only: CIN = 3, the image, which takes no gradient): the wide operand is not given but made on the way
+// into LDS -- dy = BatchNorm2+LeakyReLU backward of (dr, y2) with the finished dgamma / dbeta (the arithmetic of
+// bn_bwd_apply_kernel, term for term) -- so dy2 is never written or read: one 629 MB write + read and one launch less per call.
+// A thread keeps one 4-channel group for all its pieces (t % 6), so the group's constants stay in registers.
+struct BnApply {
+  const float* y;          // y2 [pixels][24]
+  const float* mi;         // mean[24] | invstd[24]
+  const float* gamma;
+  const float* beta;
+  const float* dgamma;     // finished sums (mmi_bn_act_bwd with dy = NULL)
+  const float* dbeta;
+  float inv_rows;
+  int frozen;
+};
+template <int CIN, int COUT, bool VEC, bool BNF = false>
 __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ dy, int ldy,
-                                                              float* __restrict__ partials, int N, int H, int W) {
+                                                              float* __restrict__ partials, int N, int H, int W, BnApply bn) {
   static_assert((CIN == 3) != (COUT == 3), "one side has 3 channels");
+  static_assert(!BNF || (CIN == 3 && VEC), "the fused BatchNorm backward is conv2's");
   constexpr bool XN = CIN == 3;                    // x is the narrow operand (conv2: 3 -> 24), else dy is (conv3: 24 -> 3)
   constexpr int WIDE = XN ? COUT : CIN;            // 24
   constexpr int NOUT = COUT * 9 * CIN;
   constexpr int XE = XN ? 4 : CIN, DE = XN ? COUT : 4;   // floats per pixel in LDS
   constexpr int XP = (TS + 2) * (TS + 2), DP = TS * TS;  // pixels of the two tiles (x with its halo)
   constexpr int WP = XN ? DP : XP, NP_ = XN ? XP : DP;   // pixels of the wide / narrow tile
-  constexpr int WV = (WP * 6 + 255) / 256;               // 16-byte pieces of the wide tile per thread
+  constexpr int WV = BNF ? (WP + 41) / 42 : (WP * 6 + 255) / 256;   // 16-byte pieces of the wide tile per thread (BNF: 42 pixels x 6 groups per round)
   constexpr int NV = (NP_ + 255) / 256;                  // narrow pixels per thread
   __shared__ __align__(16) float xs[XP * XE];
   __shared__ __align__(16) float ds[DP * DE];
@@ -117,10 +132,37 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __res
   const float* nsrc = XN ? x : dy;
   const int ldw = XN ? ldy : ldx, ldn = XN ? ldx : ldy;
   f32x4 wreg[WV];
+  f32x4 yreg[BNF ? WV : 1];
+  unsigned wmask = 0;                                    // (BNF) bit i: piece i of the loaded tile lies inside the image
   float nreg[NV][3];
+  const int bcg = t % 6, bpg = t / 6;                    // (BNF) channel group and first pixel of the thread
+  f32x4 cm, cis, cga, cbe, ck1, ck2;
+  if constexpr (BNF) {
+    const int c = bcg * 4;
+    cm = *reinterpret_cast<const f32x4*>(bn.mi + c);
+    cis = *reinterpret_cast<const f32x4*>(bn.mi + 24 + c);
+    cga = *reinterpret_cast<const f32x4*>(bn.gamma + c);
+    cbe = *reinterpret_cast<const f32x4*>(bn.beta + c);
+    ck1 = *reinterpret_cast<const f32x4*>(bn.dbeta + c);
+    ck2 = *reinterpret_cast<const f32x4*>(bn.dgamma + c);
+  }
   auto gload = [&](int tile) {
     const int n = tile / (tw * th), r = tile - n * tw * th;
     const int h0 = (r / tw) * TS, w0 = (r % tw) * TS;
+    if constexpr (BNF) {
+      wmask = 0;
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int p = bpg + i * 42, ih = h0 + p / TS, iw = w0 + p % TS;
+        wreg[i] = yreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < 252 && p < WP && ih < H && iw < W) {
+          wmask |= 1u << i;
+          const int64_t off = (((int64_t)n * H + ih) * W + iw) * 24 + bcg * 4;
+          wreg[i] = *reinterpret_cast<const f32x4*>(wsrc + off);
+          yreg[i] = *reinterpret_cast<const f32x4*>(bn.y + off);
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = t + i * 256, p = v / 6, c4 = (v - p * 6) * 4;
@@ -133,6 +175,7 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __res
           else wreg[i] = f32x4{src[0], src[1], src[2], src[3]};
         }
       }
+    }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -152,10 +195,26 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __res
   auto lstore = [&]() {
     float* wdst = XN ? ds : xs;
     float* ndst = XN ? xs : ds;
+    if constexpr (BNF) {
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int p = bpg + i * 42;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {      // (bn_bwd_apply_kernel's arithmetic; zero for the pixels of the tile outside the image)
+          const float xh = (yreg[i][k] - cm[k]) * cis[k];
+          const float dz = wreg[i][k] * ((xh * cga[k] + cbe[k]) > 0.f ? 1.0f : 0.1f);
+          const float tt = bn.frozen ? dz : dz - ck1[k] * bn.inv_rows - xh * ck2[k] * bn.inv_rows;
+          o[k] = (wmask >> i & 1u) ? cga[k] * cis[k] * tt : 0.f;
+        }
+        if (t < 252 && p < WP) *reinterpret_cast<f32x4*>(wdst + (p * 6 + bcg) * 4) = o;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = t + i * 256;
       if (v < WP * 6) *reinterpret_cast<f32x4*>(wdst + v * 4) = wreg[i];      // [pixel][24]: piece v lies at float 4 v
+    }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -320,7 +379,7 @@ struct CemOut {
   float* y3;
   float* stat_part;
 };
-template <int OB, bool Y2S, int WPE>
+template <int OB, bool Y2S, int WPE, bool FROMY2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void cem_fused_fwd_kernel(const float* __restrict__ px, const float* __restrict__ pw2,
                                                             const float* __restrict__ pmi2, const float* __restrict__ pg2,
                                                             const float* __restrict__ pb2, const float* __restrict__ pfactor,
@@ -339,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // position needs r at that position and the channel sums of its neighbours, which live in cs): no separate t tile, 52 KB of LDS
   // instead of 77, three workgroups per CU instead of two.
   constexpr int RP = 28;
-  __shared__ float xs[XS * XS * 3];
+  __shared__ float xs[FROMY2 ? 4 : XS * XS * 3];
   __shared__ __align__(16) float rs[RS * RS * RP];
   __shared__ float cs[RS * RS];
   // y2 (conv2's raw output, kept for the backward) goes to HBM through LDS: a thread of the conv2 phase owns two positions and
@@ -348,25 +407,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // the kernel's time.  From the tile in LDS the same bytes leave as 16-byte lane accesses over contiguous 1.5 KB runs.
   // (Y2S = false, OB = 4 only: a position's four channels of an iteration leave as one 16-byte store from registers -- a
   //  quarter of the LDS form's instructions again at stride 96 B, but no 24 KB tile: three workgroups per CU)
-  static_assert(Y2S || OB == 4, "direct y2 stores need four channels per iteration");
-  __shared__ __align__(16) float y2s[Y2S ? TS * TS * 24 : 4];
+  static_assert(Y2S || OB == 4 || FROMY2, "direct y2 stores need four channels per iteration");
+  __shared__ __align__(16) float y2s[Y2S && !FROMY2 ? TS * TS * 24 : 4];
   __shared__ float red[2][4][3];
   const int t = threadIdx.x, n = blockIdx.z;
   const int h0 = blockIdx.y * TS, w0 = blockIdx.x * TS;
   const int H = p.H, W = p.W;
-  {      // (all six loads of a thread in flight at once: as a rolled loop each waited for its own HBM round trip)
-    constexpr int NX = (XS * XS * 3 + 255) / 256;
-    float xv[NX];
+  if constexpr (FROMY2) {
+    // Training (second half; the first is cem_conv2_fwd_kernel): r = LeakyReLU(BN2(y2)) on the 20x20 region from the STORED y2, two
+    // positions per thread, all twelve 16-byte loads of a thread in flight together.  Same arithmetic on the same y2 as the
+    // recomputing form, so r, t and y3 are bit-identical to it.
+    if (t < RS * RS / 2) {
+      f32x4 yv[2][6];
+      int qq[2];
+      bool in[2], interior[2];
+      int64_t pix[2];
 #pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const int e = t + u * 256, c = e % 3, q = e / 3, ih = h0 - 3 + q / XS, iw = w0 - 3 + q % XS;
-      xv[u] = (e < XS * XS * 3 && ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        qq[h] = t + h * (RS * RS / 2);
+        const int i = qq[h] / RS, j = qq[h] % RS, ih = h0 - 2 + i, iw = w0 - 2 + j;
+        in[h] = ih >= 0 && iw >= 0 && ih < H && iw < W;
+        interior[h] = in[h] && i >= 2 && i < RS - 2 && j >= 2 && j < RS - 2;
+        pix[h] = ((int64_t)n * H + ih) * W + iw;
+        const float* src = p.y2 + pix[h] * 24;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) yv[h][g] = in[h] ? *reinterpret_cast<const f32x4*>(src + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int o = g * 4 + k;
+            const float z = (yv[h][g][k] - p.mi2[o]) * p.mi2[24 + o] * p.g2[o] + p.b2[o];
+            v[k] = in[h] ? (z > 0.f ? z : 0.1f * z) : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(rs + qq[h] * RP + g * 4) = v;
+          sum += (v[0] + v[1]) + (v[2] + v[3]);       // (the grouping of chansum_kernel)
+        }
+        cs[qq[h]] = sum;
+        if (p.chansum != nullptr && interior[h]) p.chansum[pix[h]] = sum;
+      }
     }
+  } else {
+    {      // (all six loads of a thread in flight at once: as a rolled loop each waited for its own HBM round trip)
+      constexpr int NX = (XS * XS * 3 + 255) / 256;
+      float xv[NX];
 #pragma unroll
-    for (int u = 0; u < NX; ++u)
-      if (t + u * 256 < XS * XS * 3) xs[t + u * 256] = xv[u];
-  }
-  __syncthreads();
+      for (int u = 0; u < NX; ++u) {
+        const int e = t + u * 256, c = e % 3, q = e / 3, ih = h0 - 3 + q / XS, iw = w0 - 3 + q % XS;
+        xv[u] = (e < XS * XS * 3 && ih >= 0 && iw >= 0 && ih < H && iw < W) ? p.x[(((int64_t)n * H + ih) * W + iw) * p.ldx + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NX; ++u)
+        if (t + u * 256 < XS * XS * 3) xs[t + u * 256] = xv[u];
+    }
+    __syncthreads();
   // ---- r = LeakyReLU(BN2(conv2(x))) on the 20x20 region; zero outside the image.  A thread owns TWO positions (q, q + 200)
   // and keeps their accumulators as the halves of float2 registers: every FMA is a v_pk_fma_f32 whose weight operand is one
   // SGPR broadcast to both halves, i.e. twice the fp32 VALU rate of the scalar form, and the 648 weights are fetched once
@@ -451,8 +550,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       if (interior[1]) p.chansum[pix1] = sum[1];
     }
   }
+  }      // (!FROMY2)
   __syncthreads();
-  if (Y2S && p.y2 != nullptr) {
+  if (Y2S && !FROMY2 && p.y2 != nullptr) {
 #pragma unroll
     for (int e = t; e < TS * TS * 6; e += 256) {
       const int pos = e / 6, g4 = (e - pos * 6) * 4, ih = h0 + pos / TS, iw = w0 + pos % TS;
@@ -538,6 +638,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       const int sidx = t / 3, o = t - sidx * 3;
       p.stat_part[((int64_t)blk * 2 + sidx) * 3 + o] = red[sidx][0][o] + red[sidx][1][o] + red[sidx][2][o] + red[sidx][3][o];
     }
+  }
+}
+
+// ---- training forward, first half: y2 = conv2(x) computed ONCE -- stored for the backward and for the second half, with BN2's
+// batch-statistics partials on the way.  (Rounds 2-4 recomputed conv2: a statistics pre-pass that stored nothing, then again on
+// the 20x20 halo region of every 16x16 tile of the fused kernel -- 2.56 evaluations of the module's most expensive layer per
+// pixel.)  A workgroup walks 32x16 tiles; a thread owns the positions (i, j) and (i + 8, j) of a tile as the halves of float2
+// accumulators (v_pk_fma_f32, the weight one SGPR broadcast to both halves), four output channels per group so that a position's
+// group leaves as one 16-byte store, and keeps the running sum / sum of squares of its positions for all 24 channels in registers
+// across its tiles: the 48 wave reductions happen once per workgroup, not once per tile (they were 288 ds_bpermute per wave and
+// tile in smallconv_kernel<3, 24>).  Per-position sums keep that kernel's tap-major / channel-minor order: y2 is bit-identical.
+constexpr int C2W = 32, C2H = 16;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cem_conv2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w2,
+                                                            float* __restrict__ y2, float* __restrict__ stat_part, int ldx, int N,
+                                                            int H, int W) {
+  constexpr int XW = C2W + 2, XH = C2H + 2, XN = XW * XH * 3;
+  __shared__ float xs[XN];
+  __shared__ float red[2][4][24];
+  const int t = threadIdx.x, i0 = t >> 5, j = t & 31;
+  const int tw = (W + C2W - 1) / C2W, th = (H + C2H - 1) / C2H, ntiles = tw * th * N;
+  float s1[24], s2[24];
+#pragma unroll
+  for (int o = 0; o < 24; ++o) s1[o] = s2[o] = 0.f;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tw * th), rt = tile - n * tw * th, h0 = (rt / tw) * C2H, w0 = (rt % tw) * C2W;
+    __syncthreads();                     // the previous tile's patches have been read
+    {
+      constexpr int NX = (XN + 255) / 256;
+      float xv[NX];
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int e = t + u * 256, c = e % 3, q = e / 3, ih = h0 - 1 + q / XW, iw = w0 - 1 + q % XW;
+        xv[u] = (e < XN && ih >= 0 && iw >= 0 && ih < H && iw < W) ? x[(((int64_t)n * H + ih) * W + iw) * ldx + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NX; ++u)
+        if (t + u * 256 < XN) xs[t + u * 256] = xv[u];
+    }
+    __syncthreads();
+    f32x2 xin[27];
+    {
+      const float* sp0 = xs + (i0 * XW + j) * 3;
+      const float* sp1 = xs + ((i0 + 8) * XW + j) * 3;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int off = ((tap / 3) * XW + tap % 3) * 3 + c;
+          xin[tap * 3 + c] = f32x2{sp0[off], sp1[off]};
+        }
+    }
+    const bool live0 = h0 + i0 < H && w0 + j < W, live1 = h0 + i0 + 8 < H && w0 + j < W;
+    float* dst0 = y2 + (((int64_t)n * H + h0 + i0) * W + w0 + j) * 24;
+    float* dst1 = dst0 + (int64_t)8 * W * 24;
+#pragma unroll
+    for (int o0 = 0; o0 < 24; o0 += 4) {
+      // (the weight address is laundered per group: as a loop invariant hipcc fetched all 648 weights ahead of the tile loop and
+      //  kept them in VGPR lanes -- 1700 v_readlane per tile)
+      int zo = 0;
+      asm volatile("" : "+s"(zo));          // (an offset, not the pointer: a laundered pointer loses its scalar-load path)
+      const float* wg = w2 + o0 * 27 + zo;
+      f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+      for (int e = 0; e < 27; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float w = wg[k * 27 + e];
+          acc[k] += xin[e] * f32x2{w, w};
+        }
+      if (live0) *reinterpret_cast<f32x4*>(dst0 + o0) = f32x4{acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+      if (live1) *reinterpret_cast<f32x4*>(dst1 + o0) = f32x4{acc[0][1], acc[1][1], acc[2][1], acc[3][1]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float m0 = live0 ? acc[k][0] : 0.f, m1 = live1 ? acc[k][1] : 0.f;
+        s1[o0 + k] += m0 + m1;
+        s2[o0 + k] += m0 * m0 + m1 * m1;
+      }
+    }
+  }
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int o = 0; o < 24; ++o) {
+    float a = s1[o], b = s2[o];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+      a += __shfl_xor(a, k);
+      b += __shfl_xor(b, k);
+    }
+    if (lane == 0) {
+      red[0][wv][o] = a;
+      red[1][wv][o] = b;
+    }
+  }
+  __syncthreads();
+  if (t < 48) {
+    const int sidx = t / 24, o = t - sidx * 24;
+    stat_part[((int64_t)blockIdx.x * 2 + sidx) * 24 + o] = red[sidx][0][o] + red[sidx][1][o] + red[sidx][2][o] + red[sidx][3][o];
   }
 }
 
@@ -868,18 +1066,43 @@ int mmi_smallconv_wgrad(const float* dy, const float* x, float* dw, void* worksp
   float* part = (float*)workspace;
   if (d->Cin == 3) {      // (VEC: the 24-channel operand fetched with 16-byte loads)
     if (d->ldy % 4 == 0 && ((uintptr_t)dy & 15) == 0)
-      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W, BnApply{});
     else
-      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W, BnApply{});
   } else {
     if (d->ldx % 4 == 0 && ((uintptr_t)x & 15) == 0)
-      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, true>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W, BnApply{});
     else
-      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W);
+      hipLaunchKernelGGL((smallconv_wgrad_kernel<24, 3, false>), dim3(blocks), dim3(256), 0, s, x, d->ldx, dy, d->ldy, part, d->N, d->H, d->W, BnApply{});
   }
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel)");
   hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(nout, 16)), dim3(256), 0, s, (const float*)part, blocks, nout, dw);
   MMI_CHECK_LAUNCH("mmi_conv_wgrad(small-channel reduce)");
+  return MMI_OK;
+}
+
+// conv2's weight gradient with BatchNorm2 + LeakyReLU's backward applied on the way in (BNF above): dw2 = wgrad(x, dy2(dr, y2)).
+// dgamma2 / dbeta2 are the finished sums (mmi_bn_act_bwd with dy = NULL, same stream, before this call).
+extern "C" size_t mmi_cem_conv2_wgrad_bn_workspace(int N, int H, int W) {
+  const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
+  return (size_t)(tiles < WG_BLOCKS ? tiles : WG_BLOCKS) * 24 * 9 * 3 * sizeof(float);
+}
+extern "C" int mmi_cem_conv2_wgrad_bn(const float* dr, const float* y2, const float* x, int ldx, const float* mean_invstd2,
+                                      const float* gamma2, const float* beta2, const float* dgamma2, const float* dbeta2, int frozen,
+                                      float* dw2, void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(dr && y2 && x && mean_invstd2 && gamma2 && beta2 && dgamma2 && dbeta2 && dw2 && workspace && N > 0 && H > 0 && W > 0 &&
+                    ldx >= 3, "mmi_cem_conv2_wgrad_bn: bad arguments");
+  MMI_CHECK_ARG((((uintptr_t)dr | (uintptr_t)y2 | (uintptr_t)mean_invstd2 | (uintptr_t)gamma2 | (uintptr_t)beta2 | (uintptr_t)dgamma2 |
+                  (uintptr_t)dbeta2) & 15) == 0, "mmi_cem_conv2_wgrad_bn: operands must be 16-byte aligned");
+  MMI_CHECK_ARG(workspace_bytes >= mmi_cem_conv2_wgrad_bn_workspace(N, H, W), "mmi_cem_conv2_wgrad_bn: workspace too small");
+  const int tiles = N * cdiv(H, TS) * cdiv(W, TS), blocks = tiles < WG_BLOCKS ? tiles : WG_BLOCKS;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const BnApply bn{y2, mean_invstd2, gamma2, beta2, dgamma2, dbeta2, 1.0f / (float)((int64_t)N * H * W), frozen};
+  hipLaunchKernelGGL((smallconv_wgrad_kernel<3, 24, true, true>), dim3(blocks), dim3(256), 0, s, x, ldx, dr, 24, part, N, H, W, bn);
+  MMI_CHECK_LAUNCH("mmi_cem_conv2_wgrad_bn");
+  hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(24 * 27, 16)), dim3(256), 0, s, (const float*)part, blocks, 24 * 27, dw2);
+  MMI_CHECK_LAUNCH("mmi_cem_conv2_wgrad_bn(reduce)");
   return MMI_OK;
 }
 
@@ -953,7 +1176,7 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
     const char* e = getenv("MMIDET_CEM_FORM");
     return e ? atoi(e) : 1;
   }();
-#define CEM_LAUNCH(OB_, Y2S_, WPE_) hipLaunchKernelGGL((cem_fused_fwd_kernel<OB_, Y2S_, WPE_>), grid, dim3(256), 0, (hipStream_t)stream, x, w2, \
+#define CEM_LAUNCH(OB_, Y2S_, WPE_) hipLaunchKernelGGL((cem_fused_fwd_kernel<OB_, Y2S_, WPE_, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w2, \
                                            mean_invstd2, gamma2, beta2, factor, sobel_bias, w3, out, ldx, H, W)
   if (form == 1) CEM_LAUNCH(4, false, 3);
   else if (ob == 2) CEM_LAUNCH(2, true, 2);
@@ -961,6 +1184,37 @@ extern "C" int mmi_cem_fused_fwd(const float* x, int ldx, const float* w2, const
   else CEM_LAUNCH(4, true, 2);
 #undef CEM_LAUNCH
   MMI_CHECK_LAUNCH("mmi_cem_fused_fwd");
+  return MMI_OK;
+}
+
+// Training forward in two launches (the default since round 4): y2 = conv2(x) with BN2's statistics partials
+// [mmi_cem_conv2_fwd_blocks][2][24], then (after mmi_bn_finalize) everything from y2 to y3 with r and t in LDS.
+extern "C" int mmi_cem_conv2_fwd_blocks(int N, int H, int W) {
+  const int tiles = N * cdiv(H, C2H) * cdiv(W, C2W);
+  return cdiv(tiles, cdiv(tiles, 1024));      // <= 1024 workgroups with equal shares of the tiles (to within one)
+}
+
+extern "C" int mmi_cem_conv2_fwd(const float* x, int ldx, const float* w2, float* y2, float* stat_partials, int N, int H, int W,
+                                 void* stream) {
+  MMI_CHECK_ARG(x && w2 && y2 && stat_partials && N > 0 && H > 0 && W > 0 && ldx >= 3, "mmi_cem_conv2_fwd: bad arguments");
+  MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0, "mmi_cem_conv2_fwd: y2 must be 16-byte aligned");
+  hipLaunchKernelGGL(cem_conv2_fwd_kernel, dim3(mmi_cem_conv2_fwd_blocks(N, H, W)), dim3(256), 0, (hipStream_t)stream, x, w2, y2,
+                     stat_partials, ldx, N, H, W);
+  MMI_CHECK_LAUNCH("mmi_cem_conv2_fwd");
+  return MMI_OK;
+}
+
+extern "C" int mmi_cem_fwd_from_y2(const float* y2, const float* mean_invstd2, const float* gamma2, const float* beta2,
+                                   const float* factor, const float* sobel_bias, const float* w3, float* t, float* chansum, float* y3,
+                                   float* stat_partials3, int N, int H, int W, void* stream) {
+  MMI_CHECK_ARG(y2 && mean_invstd2 && gamma2 && beta2 && factor && sobel_bias && w3 && y3 && N > 0 && H > 0 && W > 0,
+                "mmi_cem_fwd_from_y2: bad arguments");
+  MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0 && ((uintptr_t)t & 15) == 0, "mmi_cem_fwd_from_y2: y2 / t must be 16-byte aligned");
+  const CemOut out{const_cast<float*>(y2), t, chansum, y3, stat_partials3};
+  const dim3 grid(cdiv(W, TS), cdiv(H, TS), N);
+  hipLaunchKernelGGL((cem_fused_fwd_kernel<4, false, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                     (const float*)nullptr, mean_invstd2, gamma2, beta2, factor, sobel_bias, w3, out, 0, H, W);
+  MMI_CHECK_LAUNCH("mmi_cem_fwd_from_y2");
   return MMI_OK;
 }
 

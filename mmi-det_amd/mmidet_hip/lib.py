@@ -167,6 +167,11 @@ _SIGS = {
     'mmi_cem_bwd_mid_blocks': (c_int, [c_int, c_int, c_int]),
     'mmi_cem_bwd_mid': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'mmi_cem_conv2_stats': (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
+    'mmi_cem_conv2_fwd_blocks': (c_int, [c_int, c_int, c_int]),
+    'mmi_cem_conv2_wgrad_bn_workspace': (c_size_t, [c_int, c_int, c_int]),
+    'mmi_cem_conv2_wgrad_bn': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, P, P, c_size_t, c_int, c_int, c_int, P]),
+    'mmi_cem_conv2_fwd': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, P]),
+    'mmi_cem_fwd_from_y2': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'mmi_cem_fused_fwd': (c_int, [P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'mmi_comm_available': (c_int, []),
     'mmi_comm_unique_id': (c_int, [P]),
@@ -184,7 +189,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_conv2_fwd_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

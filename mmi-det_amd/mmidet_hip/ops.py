@@ -1062,6 +1062,12 @@ CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"
 # ... with BatchNorm2's backward reduction riding along: correct (tests/test_cem_gpu.py) but 48 more accumulators cost the kernel a
 # workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
 CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "0") == "1"
+# Training forward as conv2 (stored, with BN2's statistics) + the fused kernel reading y2: conv2 evaluated once instead of 2.56 times
+# per pixel; bit-identical results (tests/test_cem_gpu.py).  "0": statistics pre-pass + recomputing fused kernel (rounds 2-3).
+CEM_TWO_PASS = __import__("os").environ.get("MMIDET_CEM_TWO_PASS", "1") != "0"
+# BatchNorm2's backward apply pass inside conv2's weight-gradient loader (the image takes no gradient, so dy2 has no other reader):
+# dy2 never reaches HBM.  "0": the separate apply pass + the generic small-channel weight gradient.
+CEM_WGRAD_BN = __import__("os").environ.get("MMIDET_CEM_WGRAD_BN", "1") != "0"
 
 
 class _CemFused(Function):
@@ -1081,21 +1087,30 @@ class _CemFused(Function):
         f = factor.reshape(-1).contiguous()
         mi2 = alloc.empty(48, dtype=torch.float32, device=dev)
         mi3 = alloc.empty(6, dtype=torch.float32, device=dev)
-        if training:
-            part = scratch((nblk + 64) * 2 * 24, dev)
-            lib.cem_conv2_stats(x.data_ptr(), ldx, w2.data_ptr(), part.data_ptr(), n, h, w, s)
-            lib.bn_finalize(part.data_ptr(), nblk, rows, 24, eps, momentum, rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr(), mi2.data_ptr(), s)
-        else:
-            lib.bn_eval_stats(rm2.data_ptr(), rv2.data_ptr(), 24, eps, mi2.data_ptr(), s)
         keep = any(ctx.needs_input_grad)      # (grad mode itself is off inside forward)
         y2 = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
         t = alloc.empty((n, h, w, 24), dtype=torch.float32, device=dev) if keep else None
         cs = alloc.empty((n, h, w), dtype=torch.float32, device=dev) if keep else None
         y3 = alloc.empty((n, h, w, 3), dtype=torch.float32, device=dev)
         part3 = scratch((nblk + 64) * 2 * 3, dev, slot=6) if training else None
-        lib.cem_fused_fwd(x.data_ptr(), ldx, w2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), f.data_ptr(), sbias.data_ptr(),
-                          w3.data_ptr(), y2.data_ptr() if keep else None, t.data_ptr() if keep else None, cs.data_ptr() if keep else None,
-                          y3.data_ptr(), part3.data_ptr() if training else None, n, h, w, s)
+        two_pass = training and keep and CEM_TWO_PASS
+        if two_pass:
+            nb2 = lib.cem_conv2_fwd_blocks(n, h, w)
+            part = scratch((nb2 + 64) * 2 * 24, dev)
+            lib.cem_conv2_fwd(x.data_ptr(), ldx, w2.data_ptr(), y2.data_ptr(), part.data_ptr(), n, h, w, s)
+            lib.bn_finalize(part.data_ptr(), nb2, rows, 24, eps, momentum, rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr(), mi2.data_ptr(), s)
+            lib.cem_fwd_from_y2(y2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), f.data_ptr(), sbias.data_ptr(), w3.data_ptr(),
+                                t.data_ptr(), cs.data_ptr(), y3.data_ptr(), part3.data_ptr(), n, h, w, s)
+        else:
+            if training:
+                part = scratch((nblk + 64) * 2 * 24, dev)
+                lib.cem_conv2_stats(x.data_ptr(), ldx, w2.data_ptr(), part.data_ptr(), n, h, w, s)
+                lib.bn_finalize(part.data_ptr(), nblk, rows, 24, eps, momentum, rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr(), mi2.data_ptr(), s)
+            else:
+                lib.bn_eval_stats(rm2.data_ptr(), rv2.data_ptr(), 24, eps, mi2.data_ptr(), s)
+            lib.cem_fused_fwd(x.data_ptr(), ldx, w2.data_ptr(), mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), f.data_ptr(), sbias.data_ptr(),
+                              w3.data_ptr(), y2.data_ptr() if keep else None, t.data_ptr() if keep else None, cs.data_ptr() if keep else None,
+                              y3.data_ptr(), part3.data_ptr() if training else None, n, h, w, s)
         if training:
             lib.bn_finalize(part3.data_ptr(), nblk, rows, 3, eps, momentum, rm3.data_ptr(), rv3.data_ptr(), nbt3.data_ptr(), mi3.data_ptr(), s)
         else:
@@ -1146,8 +1161,34 @@ class _CemFused(Function):
             lib.sobel_add_bwd(dt.data_ptr(), 24, cs.data_ptr(), f.data_ptr(), dr.data_ptr(), 24, df.data_ptr(), dsb.data_ptr(),
                               ws.data_ptr(), n, h, w, 24, s)
         # BN2 + LeakyReLU
-        dy2 = alloc.empty_like(y2)
         dg2, db2 = grad_like(g2), grad_like(b2)
+        if CEM_WGRAD_BN and not ctx.needs_input_grad[0] and not (CEM_BWD_FUSED and CEM_BWD_BN):
+            # sums only, then the apply pass inside conv2's weight-gradient loader (csrc/cem.hip, BNF)
+            nbw = bn_bwd_ws(rows, 24)
+            ws2 = zeroed_scratch(nbw, dev, s, tag='bn')
+            lib.bn_act_bwd(y2.data_ptr(), 24, dr.data_ptr(), 24, None, 0, 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), ws2.data_ptr(),
+                           nbw, None, 24, dg2.data_ptr(), db2.data_ptr(), None, None, rows, 24, ACT_LEAKY, frozen, s)
+            dw2 = grad_like(w2)
+            nb = lib.cem_conv2_wgrad_bn_workspace(n, h, w)
+
+            def launch(st, wsp):
+                lib.cem_conv2_wgrad_bn(dr.data_ptr(), y2.data_ptr(), x.data_ptr(), ldx, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                       dg2.data_ptr(), db2.data_ptr(), frozen, dw2.data_ptr(), wsp, nb, n, h, w, st)
+            if OVERLAP_WGRAD:
+                main, side = torch.cuda.current_stream(), _side_stream(dev)
+                side.wait_stream(main)
+                launch(side.cuda_stream, scratch(nb // 4, dev, slot=8, stream=side.cuda_stream).data_ptr())
+                if DEFER_JOIN:
+                    _pending.append((dr, y2, x, dg2, db2))
+                    _pending_sides[side.cuda_stream] = side
+            else:
+                launch(s, scratch(nb // 4, dev, slot=8).data_ptr())
+            if dw3 is None:
+                dw3 = _wgrad(dy3, 3, t, 24, w3, d3, overlap=OVERLAP_WGRAD)
+            if OVERLAP_WGRAD:
+                _join_side(dev)
+            return (None, dw2, dg2, db2, None, None, None, df.view(fshape), dsb, dw3, dg3, db3, None, None, None, None, None, None)
+        dy2 = alloc.empty_like(y2)
         if CEM_BWD_FUSED and CEM_BWD_BN:     # the reduction came out of cem_bwd_mid: fold its partials, then the apply pass
             lib.bn_act_bwd_apply(y2.data_ptr(), 24, dr.data_ptr(), 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr(),
                                  lib.cem_bwd_mid_blocks(n, h, w), dy2.data_ptr(), 24, dg2.data_ptr(), db2.data_ptr(), rows, 24, ACT_LEAKY,
