@@ -472,7 +472,8 @@ int mmi_cem_conv2_stats(const float* x, int ldx, const float* w2, float* stat_pa
 /* Training forward in two launches (round 4; conv2 is evaluated once instead of 2.56 times per pixel): y2 = conv2(x) stored, with
  * BN2's statistics partials [mmi_cem_conv2_fwd_blocks][2][24] -> mmi_bn_finalize; then y2 -> r -> t -> y3 (mmi_cem_fwd_from_y2:
  * the fused kernel reading y2 instead of recomputing it; t / chansum written when non-NULL, y3 statistics partials
- * [mmi_cem_blocks][2][3]).  Results are bit-identical to mmi_cem_conv2_stats + mmi_cem_fused_fwd. */
+ * [mmi_cem_blocks][2][3]).  y2, and for the same BN2 statistics t / chansum / y3 and its partials, are bit-identical to
+ * mmi_cem_fused_fwd's; the BN2 statistics themselves are sums of differently grouped partials (equal to rounding). */
 /* conv2's weight gradient with BatchNorm2 + LeakyReLU's backward applied in the loader (the image takes no gradient, so dy2 has no
  * other reader): dw2 = wgrad(x, dy2(dr, y2)), dy2 never in HBM.  dgamma2 / dbeta2: finished by mmi_bn_act_bwd(..., dy = NULL, ...)
  * earlier on the same stream.  Workspace: mmi_cem_conv2_wgrad_bn_workspace bytes (plain scratch, no counters). */

@@ -138,13 +138,16 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const float* __res
   const int bcg = t % 6, bpg = t / 6;                    // (BNF) channel group and first pixel of the thread
   f32x4 cm, cis, cga, cbe, ck1, ck2;
   if constexpr (BNF) {
-    const int c = bcg * 4;
-    cm = *reinterpret_cast<const f32x4*>(bn.mi + c);
-    cis = *reinterpret_cast<const f32x4*>(bn.mi + 24 + c);
-    cga = *reinterpret_cast<const f32x4*>(bn.gamma + c);
-    cbe = *reinterpret_cast<const f32x4*>(bn.beta + c);
-    ck1 = *reinterpret_cast<const f32x4*>(bn.dbeta + c);
-    ck2 = *reinterpret_cast<const f32x4*>(bn.dgamma + c);
+    const int c = bcg * 4;      // (dword loads: parameters and their gradients may sit at any 4-byte offset of a packed buffer / bucket)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cm[k] = bn.mi[c + k];
+      cis[k] = bn.mi[24 + c + k];
+      cga[k] = bn.gamma[c + k];
+      cbe[k] = bn.beta[c + k];
+      ck1[k] = bn.dbeta[c + k];
+      ck2[k] = bn.dgamma[c + k];
+    }
   }
   auto gload = [&](int tile) {
     const int n = tile / (tw * th), r = tile - n * tw * th;
@@ -1092,8 +1095,7 @@ extern "C" int mmi_cem_conv2_wgrad_bn(const float* dr, const float* y2, const fl
                                       float* dw2, void* workspace, size_t workspace_bytes, int N, int H, int W, void* stream) {
   MMI_CHECK_ARG(dr && y2 && x && mean_invstd2 && gamma2 && beta2 && dgamma2 && dbeta2 && dw2 && workspace && N > 0 && H > 0 && W > 0 &&
                     ldx >= 3, "mmi_cem_conv2_wgrad_bn: bad arguments");
-  MMI_CHECK_ARG((((uintptr_t)dr | (uintptr_t)y2 | (uintptr_t)mean_invstd2 | (uintptr_t)gamma2 | (uintptr_t)beta2 | (uintptr_t)dgamma2 |
-                  (uintptr_t)dbeta2) & 15) == 0, "mmi_cem_conv2_wgrad_bn: operands must be 16-byte aligned");
+  MMI_CHECK_ARG((((uintptr_t)dr | (uintptr_t)y2) & 15) == 0, "mmi_cem_conv2_wgrad_bn: dr / y2 must be 16-byte aligned");
   MMI_CHECK_ARG(workspace_bytes >= mmi_cem_conv2_wgrad_bn_workspace(N, H, W), "mmi_cem_conv2_wgrad_bn: workspace too small");
   const int tiles = N * cdiv(H, TS) * cdiv(W, TS), blocks = tiles < WG_BLOCKS ? tiles : WG_BLOCKS;
   hipStream_t s = (hipStream_t)stream;
@@ -1219,7 +1221,18 @@ extern "C" int mmi_cem_fwd_from_y2(const float* y2, const float* mean_invstd2, c
 }
 
 // ---- fused middle of the CEM backward: host side -----------------------------------------------------------------------
-constexpr int CEM_MID_BLOCKS = 1024;
+// Workgroups of the persistent grid: 512 = two per CU.  Module time at 16 x 640 x 640 on one box (profiles/r04_cem_bwd_mid_grid.txt):
+// 2.47 ms at 1024 (rounds 2-3), 2.45 at 768, 2.44 at 512, 2.47 at 384, 2.63 at 256.  (Also tried in round 4 and dropped: a 28-float
+// LDS pitch for dt, the staging loads unrolled, dr staged through LDS for contiguous stores -- each neutral or slower here.)
+static int cem_mid_blocks_max() {
+  static const int v = [] {
+    const char* e = getenv("MMIDET_CEM_MID_BLOCKS");
+    const int n = e ? atoi(e) : 512;
+    return n >= 64 && n <= 4096 ? n : 512;
+  }();
+  return v;
+}
+#define CEM_MID_BLOCKS cem_mid_blocks_max()
 extern "C" size_t mmi_cem_bwd_mid_workspace(int N, int H, int W) {
   const int tiles = N * cdiv(H, TS) * cdiv(W, TS);
   return (size_t)(tiles < CEM_MID_BLOCKS ? tiles : CEM_MID_BLOCKS) * 2 * 24 * sizeof(float);

@@ -1063,7 +1063,7 @@ CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"
 # workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
 CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "0") == "1"
 # Training forward as conv2 (stored, with BN2's statistics) + the fused kernel reading y2: conv2 evaluated once instead of 2.56 times
-# per pixel; bit-identical results (tests/test_cem_gpu.py).  "0": statistics pre-pass + recomputing fused kernel (rounds 2-3).
+# per pixel; same arithmetic on the same y2 (tests/test_cem_gpu.py).  "0": statistics pre-pass + recomputing fused kernel (rounds 2-3).
 CEM_TWO_PASS = __import__("os").environ.get("MMIDET_CEM_TWO_PASS", "1") != "0"
 # BatchNorm2's backward apply pass inside conv2's weight-gradient loader (the image takes no gradient, so dy2 has no other reader):
 # dy2 never reaches HBM.  "0": the separate apply pass + the generic small-channel weight gradient.
@@ -1179,7 +1179,7 @@ class _CemFused(Function):
                 side.wait_stream(main)
                 launch(side.cuda_stream, scratch(nb // 4, dev, slot=8, stream=side.cuda_stream).data_ptr())
                 if DEFER_JOIN:
-                    _pending.append((dr, y2, x, dg2, db2))
+                    _pending.append((dr, y2, x))      # (not dg2 / db2: a second owner makes AccumulateGrad clone a bucket view instead of adopting it)
                     _pending_sides[side.cuda_stream] = side
             else:
                 launch(s, scratch(nb // 4, dev, slot=8).data_ptr())

@@ -186,3 +186,89 @@ def test_fused_backward_middle_matches_the_two_step_form(shape):
     close(dg_got, dg_ref, what='dgamma2', tol=2e-5)
     close(dbt_got, dbt_ref, what='dbeta2', tol=2e-5)
     close(dy_got, dy_ref, what='dy2', tol=2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 40), (1, 33, 17), (3, 5, 3), (1, 16, 16), (2, 130, 70)])
+def test_two_launch_training_forward_equals_the_recomputing_form(shape):
+    """Round 4: conv2 evaluated once.  mmi_cem_conv2_fwd's y2 and mmi_cem_fwd_from_y2's t / chansum / y3 / statistics partials are
+    BIT-identical to what mmi_cem_fused_fwd (which recomputes conv2 on every tile's halo region) writes for the same BN2 statistics;
+    BN2's batch statistics themselves come from differently grouped partial sums, so they agree to rounding."""
+    from mmidet_hip import lib
+    n, h, w = shape
+    d = dev()
+    g = torch.Generator().manual_seed(h * 5 + w)
+    x = torch.rand(n, h, w, 3, generator=g).to(d)
+    w2 = (torch.randn(24, 3, 3, 3, generator=g) * 0.3).to(d)          # OHWI [24][9][3]
+    w3 = (torch.randn(3, 3, 3, 24, generator=g) * 0.2).to(d)          # OHWI [3][9][24]
+    f, sb = (torch.rand(24, generator=g) + 0.5).to(d), (torch.randn(24, generator=g) * 0.1).to(d)
+    gam, bet = (torch.rand(24, generator=g) + 0.5).to(d), (torch.randn(24, generator=g) * 0.2).to(d)
+    s = torch.cuda.current_stream().cuda_stream
+    rows, nblk = n * h * w, lib.cem_blocks(n, h, w)
+    rm, rv, nbt = torch.zeros(24, device=d), torch.ones(24, device=d), torch.zeros((), dtype=torch.int64, device=d)
+
+    def stats(launch, blocks):
+        part = torch.zeros((blocks + 64) * 48, device=d)
+        launch(part)
+        mi = torch.empty(48, device=d)
+        lib.bn_finalize(part.data_ptr(), blocks, rows, 24, 1e-5, 0.1, rm.clone().data_ptr(), rv.clone().data_ptr(), nbt.clone().data_ptr(),
+                        mi.data_ptr(), s)
+        return mi
+    y2b = torch.full((n, h, w, 24), float('nan'), device=d)
+    mi_a = stats(lambda p: lib.cem_conv2_stats(x.data_ptr(), 3, w2.data_ptr(), p.data_ptr(), n, h, w, s), nblk)
+    mi_b = stats(lambda p: lib.cem_conv2_fwd(x.data_ptr(), 3, w2.data_ptr(), y2b.data_ptr(), p.data_ptr(), n, h, w, s),
+                 lib.cem_conv2_fwd_blocks(n, h, w))
+    close(mi_b, mi_a, what='BN2 mean | invstd', tol=2e-6)
+
+    def outs():
+        return (torch.full((n, h, w, 24), float('nan'), device=d), torch.full((n, h, w), float('nan'), device=d),
+                torch.full((n, h, w, 3), float('nan'), device=d), torch.zeros((nblk + 64) * 6, device=d))
+    y2a = torch.full((n, h, w, 24), float('nan'), device=d)
+    ta, ca, y3a, pa = outs()
+    lib.cem_fused_fwd(x.data_ptr(), 3, w2.data_ptr(), mi_a.data_ptr(), gam.data_ptr(), bet.data_ptr(), f.data_ptr(), sb.data_ptr(), w3.data_ptr(),
+                      y2a.data_ptr(), ta.data_ptr(), ca.data_ptr(), y3a.data_ptr(), pa.data_ptr(), n, h, w, s)
+    tb, cb, y3b, pb = outs()
+    lib.cem_fwd_from_y2(y2b.data_ptr(), mi_a.data_ptr(), gam.data_ptr(), bet.data_ptr(), f.data_ptr(), sb.data_ptr(), w3.data_ptr(),
+                        tb.data_ptr(), cb.data_ptr(), y3b.data_ptr(), pb.data_ptr(), n, h, w, s)
+    torch.cuda.synchronize()
+    assert torch.equal(y2b, y2a), 'y2'
+    assert torch.equal(tb, ta) and torch.equal(cb, ca), 't / chansum'
+    assert torch.equal(y3b, y3a) and torch.equal(pb, pa), 'y3 / its statistics partials'
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 40), (1, 33, 17), (3, 5, 3), (1, 16, 16), (2, 130, 70)])
+@pytest.mark.parametrize('frozen', [0, 1])
+def test_conv2_weight_gradient_with_the_batchnorm_backward_in_its_loader(shape, frozen):
+    """mmi_cem_conv2_wgrad_bn (dy2 made from (dr, y2) on the way into LDS, never in HBM) against the two-step form: the one-call
+    BatchNorm backward writing dy2, then the small-channel weight gradient of (x, dy2).  Ragged tiles included: a tile's pixels
+    outside the image must contribute nothing although `dz - mean - xhat * mean` is not zero there."""
+    from mmidet_hip import lib, ops
+    from mmidet_hip.ops import ConvDesc
+    n, h, w = shape
+    d = dev()
+    g = torch.Generator().manual_seed(h * 11 + w + frozen)
+    x = torch.rand(n, h, w, 3, generator=g).to(d)
+    dr = torch.randn(n, h, w, 24, generator=g).to(d)
+    y2 = torch.randn(n, h, w, 24, generator=g).to(d)
+    mi = torch.cat([torch.randn(24, generator=g) * 0.2, torch.rand(24, generator=g) + 0.5]).to(d)
+    gam, bet = (torch.rand(24, generator=g) + 0.5).to(d), (torch.randn(24, generator=g) * 0.2).to(d)
+    s = torch.cuda.current_stream().cuda_stream
+    rows = n * h * w
+    dy2, dg0, db0 = torch.empty_like(y2), torch.empty(24, device=d), torch.empty(24, device=d)
+    ops._bn_act_bwd(y2, 24, dr, 24, None, 0, 24, mi, gam, bet, dy2, (dg0, db0, None, None), rows, 24, ops.ACT_LEAKY, frozen, s)
+    wref = torch.empty(24, 3, 3, 3, device=d).contiguous(memory_format=torch.channels_last)
+    dw0 = ops._wgrad(dy2, 24, x, 3, wref, ConvDesc(n, h, w, 3, h, w, 24, 3, 3, 1, 1, 3, 24))
+    # the fused form: sums only (dy = NULL), then the weight gradient
+    gbuf = torch.empty(64, device=d)
+    dg1, db1 = gbuf[1:25], gbuf[35:59]          # (views into a gradient bucket: any 4-byte offset)
+    nbw = ops.bn_bwd_ws(rows, 24)
+    ws = torch.zeros(nbw, dtype=torch.uint8, device=d)
+    lib.bn_act_bwd(y2.data_ptr(), 24, dr.data_ptr(), 24, None, 0, 24, mi.data_ptr(), gam.data_ptr(), bet.data_ptr(), ws.data_ptr(), nbw,
+                   None, 24, dg1.data_ptr(), db1.data_ptr(), None, None, rows, 24, ops.ACT_LEAKY, frozen, s)
+    nb = lib.cem_conv2_wgrad_bn_workspace(n, h, w)
+    wsw = torch.empty(nb // 4, device=d)
+    dw1 = torch.full((24, 9, 3), float('nan'), device=d)
+    lib.cem_conv2_wgrad_bn(dr.data_ptr(), y2.data_ptr(), x.data_ptr(), 3, mi.data_ptr(), gam.data_ptr(), bet.data_ptr(), dg1.data_ptr(),
+                           db1.data_ptr(), frozen, dw1.data_ptr(), wsw.data_ptr(), nb, n, h, w, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0), 'the sums are the same launches'
+    close(dw1.reshape(-1), dw0.permute(0, 2, 3, 1).reshape(-1), what='dw2', tol=2e-5)
