@@ -266,6 +266,35 @@ int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, float* const*
 /* dx[g] = conv_transpose(dy[g], w[g]) [+ skip[g]]; skip (row stride ldskip; may alias dx) only for 1x1 stride-1 layers, else NULL */
 int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
                     void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+/* Input gradient with the BatchNorm backward REDUCTION of the layer below in its epilogue (round 4).  dx of a convolution is the
+ * incoming gradient of the BatchNorm + activation whose output the convolution read (models/common.py:108-125: Conv = conv -> bn ->
+ * act; when that output has no other reader).  The epilogue holds the finished dx tile, so it forms dz = dx * act'(xhat * gamma + beta)
+ * and writes the partial column sums of dz and dz * xhat per row block: hook->partials[row_block][2][Cin], row blocks =
+ * mmi_conv_dgrad_row_blocks_n(d, nprob) -- the list mmi_bn_act_bwd_apply / _apply_map fold.  That BatchNorm's own backward then skips
+ * its pass over (dx, y): one read of each per layer and one launch less.  hook->y: the BatchNorm's input (the layer's raw conv output,
+ * row stride ldy), mean at mean_invstd[c], 1/std at mean_invstd[mi_stride + c].  Stride-1 MFMA layers only; skip / ldskip as
+ * mmi_conv_dgrad2 (dx = dgrad + skip, 1x1 stride-1 layers; NULL otherwise).  fp32 storage. */
+typedef struct mmi_bn_reduce_hook {
+  const float* y;
+  int ldy;
+  const float* mean_invstd;
+  int mi_stride;
+  const float* gamma;
+  const float* beta;
+  int act;
+  float* partials;
+} mmi_bn_reduce_hook;
+int mmi_conv_dgrad_row_blocks_n(const mmi_conv_desc* d, int nprob);
+int mmi_conv_dgrad_bnred(const float* dy, const float* w, float* dx, const float* skip, int ldskip, const mmi_bn_reduce_hook* hook,
+                         void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream);
+int mmi_conv_dgrad2_bnred(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                          const mmi_bn_reduce_hook* hooks, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                          void* stream);
+/* The apply pass of a mapped BatchNorm backward whose reduction came from elsewhere: parameter block i's sums are folded from
+ * partials[i][nparts][2][map->blk] into map->dgamma[i] / dbeta[i], then dy as mmi_bn_act_bwd_map writes it. */
+int mmi_bn_act_bwd_apply_map(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1, const float* mean_invstd,
+                             const mmi_bn_map* map, const float* const* partials, int nparts, float* dy, int lddy, int64_t rows, int C,
+                             int act, int frozen, void* stream);
 /* dw[g] = dy[g]^T x[g] (and dbias[g] = column sums of dy[g] when dbias != NULL); `table` as for mmi_conv_wgrad_tab (shapes only:
  * one table serves both problems) or NULL */
 int mmi_conv_wgrad2(const float* const* dy, const float* const* x, float* const* dw, float* const* dbias, void* workspace,

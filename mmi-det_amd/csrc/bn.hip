@@ -720,6 +720,21 @@ extern "C" int mmi_bn_act_bwd_map(const float* y, int ldy, const float* dout, in
                                 frozen, stream);
 }
 
+extern "C" int mmi_bn_act_bwd_apply_map(const float* y, int ldy, const float* dout, int ldd, const float* dout1, int ldd1,
+                                        const float* mean_invstd, const mmi_bn_map* map, const float* const* partials, int nparts,
+                                        float* dy, int lddy, int64_t rows, int C, int act, int frozen, void* stream) {
+  MMI_CHECK_ARG(y && dout && mean_invstd && map && partials && dy && rows > 0 && C > 0 && nparts > 0, "mmi_bn_act_bwd_apply_map: bad arguments");
+  if (int e = check_map(*map, C, true, "mmi_bn_act_bwd_apply_map")) return e;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < map->nblk; ++i) {
+    MMI_CHECK_ARG(partials[i] != nullptr, "mmi_bn_act_bwd_apply_map: null partial list (block %d)", i);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(map->blk, 16)), dim3(256), 0, s, partials[i], nparts, map->blk, map->dgamma[i],
+                       map->dbeta[i], 1);
+    MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply_map(finalize)");
+  }
+  return launch_apply<float>(y, ldy, dout, ldd, dout1, ldd1, mean_invstd, *map, dy, lddy, rows, C, act, frozen, s);
+}
+
 extern "C" int mmi_colsum(const float* x, int ldx, int64_t rows, int C, float* partials, float* out, void* stream) {
   MMI_CHECK_ARG(x && partials && out && rows > 0 && C > 0 && ldx >= C, "mmi_colsum: bad arguments");
   const int nparts = mmi_bn_bwd_parts(rows);

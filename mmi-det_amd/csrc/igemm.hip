@@ -427,6 +427,54 @@ extern "C" int mmi_conv_dgrad(const float* dy, const float* w, float* dx, void* 
   return launch_igemm<true, false>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- input gradient with the BatchNorm backward reduction of the layer below in its epilogue (IgemmP::bnr_y) ----------------
+namespace {
+void fill_dgrad(IgemmP& p, const float* dy, const float* w, float* dx, const mmi_conv_desc* d) {
+  p.A = dy; p.B = w; p.C = dx;
+  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
+  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
+  p.par = dgrad_par(d) ? 1 : 0;
+}
+int set_bn_hook(IgemmP& p, const mmi_bn_reduce_hook* h, const mmi_conv_desc* d, const char* who) {
+  MMI_CHECK_ARG(h->y && h->mean_invstd && h->gamma && h->beta && h->partials, "%s: null pointer in the BatchNorm hook", who);
+  MMI_CHECK_ARG(h->ldy >= d->Cin && h->mi_stride >= d->Cin, "%s: hook strides < Cin", who);
+  MMI_CHECK_ARG(h->act == MMI_ACT_NONE || h->act == MMI_ACT_SILU || h->act == MMI_ACT_LEAKY, "%s: unknown activation %d", who, h->act);
+  MMI_CHECK_ARG(!dgrad_par(d) && !mmi_smallconv_dgrad_supported(d), "%s: stride-1 MFMA layers only", who);
+  p.bnr_y = h->y; p.bnr_ldy = h->ldy; p.bnr_g = h->gamma; p.bnr_b = h->beta; p.bnr_act = h->act;
+  p.bn_mi = const_cast<float*>(h->mean_invstd); p.mi_stride = h->mi_stride;
+  p.stat_part = h->partials;
+  return MMI_OK;
+}
+}  // namespace
+
+extern "C" int mmi_conv_dgrad_row_blocks_n(const mmi_conv_desc* d, int nprob) {
+  const PrecScope prec_scope_(d, 1);
+  if (check_desc(d, "mmi_conv_dgrad_row_blocks_n") != MMI_OK || nprob < 1 || nprob > 2) return MMI_ERR_ARG;
+  return dgrad_plan(d, nprob).mtiles;
+}
+
+extern "C" int mmi_conv_dgrad_bnred(const float* dy, const float* w, float* dx, const float* skip, int ldskip,
+                                    const mmi_bn_reduce_hook* hook, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                                    void* stream) {
+  const PrecScope prec_scope_(d, 1);
+  const char* who = "mmi_conv_dgrad_bnred";
+  if (int e = check_desc(d, who)) return e;
+  MMI_CHECK_ARG(dy && w && dx && hook, "%s: null pointer", who);
+  const bool vec = dgrad_vec(d);
+  MMI_CHECK_ARG(!vec || (((uintptr_t)dy | (uintptr_t)w) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+  MMI_CHECK_ARG(skip == nullptr || (vec && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && ldskip >= d->Cin && ldskip % 4 == 0),
+                "%s: the skip accumulation exists for vector-shaped 1x1 stride-1 layers", who);
+  IgemmP p{};
+  fill_dgrad(p, dy, w, dx, d);
+  if (int e = set_bn_hook(p, hook, d, who)) return e;
+  if (skip != nullptr) {
+    p.epi = MMI_EPI_ACCUMULATE; p.aux = skip; p.ldaux = ldskip; p.inv_keep = 1.0f;
+    return launch_igemm<true, true>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  return launch_igemm<true, false>(p, dgrad_plan(d), vec, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // ---- twin launches ----------------------------------------------------------------------------------------------------
 // The RGB and IR backbones of the two-stream model (models/yolo_test.py:162-273 of the reference walks them layer by layer) run
 // the same layer shapes on different weights.  A twin entry point carries both problems in ONE launch (blockIdx.z = problem):
@@ -446,13 +494,6 @@ void fill_fwd(IgemmP& p, const float* x, const float* w, float* y, float* part, 
   p.M = d->N * d->Ho * d->Wo; p.Ncol = d->Cout; p.Kc = d->Cin; p.KH = d->KH; p.KW = d->KW;
   p.P = d->Ho; p.Q = d->Wo; p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.ldc = d->ldy;
   p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cin; p.ldb = p.Ktot;
-}
-void fill_dgrad(IgemmP& p, const float* dy, const float* w, float* dx, const mmi_conv_desc* d) {
-  p.A = dy; p.B = w; p.C = dx;
-  p.M = d->N * d->H * d->W; p.Ncol = d->Cin; p.Kc = d->Cout; p.KH = d->KH; p.KW = d->KW;
-  p.P = d->H; p.Q = d->W; p.Hs = d->Ho; p.Ws = d->Wo; p.lda = d->ldy; p.ldc = d->ldx;
-  p.stride = d->stride; p.pad = d->pad; p.Ktot = d->KH * d->KW * d->Cout; p.ldb = d->KH * d->KW * d->Cin;
-  p.par = dgrad_par(d) ? 1 : 0;
 }
 bool twin_shape_ok(const mmi_conv_desc* d) { return !mmi_smallconv_supported(d) && !mmi_smallconv_dgrad_supported(d); }
 }  // namespace
@@ -520,10 +561,11 @@ extern "C" int mmi_conv_bn_fwd2(const float* const* x, const float* const* w, fl
 }
 
 // dx[g] = conv_transpose(dy[g], w[g]) [+ skip[g]]; skip (row stride ldskip) only for 1x1 stride-1 layers (GEMM epilogue), else NULL
-extern "C" int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
-                               void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+namespace {
+int conv_dgrad2_impl(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                     const mmi_bn_reduce_hook* hooks, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream,
+                     const char* who) {
   const PrecScope prec_scope_(d, 1);
-  const char* who = "mmi_conv_dgrad2";
   if (int e = check_desc(d, who)) return e;
   MMI_CHECK_ARG(dy && w && dx, "%s: null argument arrays", who);
   MMI_CHECK_ARG(twin_shape_ok(d), "%s: the CEM's direct convolutions have no twin form", who);
@@ -550,9 +592,25 @@ extern "C" int mmi_conv_dgrad2(const float* const* dy, const float* const* w, fl
     if (acc) {
       p[g].epi = MMI_EPI_ACCUMULATE; p[g].aux = skip[g]; p[g].ldaux = ldskip; p[g].inv_keep = 1.0f;
     }
+    if (hooks != nullptr)
+      if (int e = set_bn_hook(p[g], hooks + g, d, who)) return e;
   }
   if (acc) return launch_igemm<true, true>(p[0], f, vec, workspace, workspace_bytes, (hipStream_t)stream, 0, &p[1]);
   return launch_igemm<true, false>(p[0], f, vec, workspace, workspace_bytes, (hipStream_t)stream, 0, &p[1]);
+}
+}  // namespace
+
+extern "C" int mmi_conv_dgrad2(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                               void* workspace, size_t workspace_bytes, const mmi_conv_desc* d, void* stream) {
+  return conv_dgrad2_impl(dy, w, dx, skip, ldskip, nullptr, workspace, workspace_bytes, d, stream, "mmi_conv_dgrad2");
+}
+
+// ... with each problem's BatchNorm backward reduction in the epilogue (hooks[2]; partial rows: mmi_conv_dgrad_row_blocks_n(d, 2))
+extern "C" int mmi_conv_dgrad2_bnred(const float* const* dy, const float* const* w, float* const* dx, const float* const* skip, int ldskip,
+                                     const mmi_bn_reduce_hook* hooks, void* workspace, size_t workspace_bytes, const mmi_conv_desc* d,
+                                     void* stream) {
+  MMI_CHECK_ARG(hooks != nullptr, "mmi_conv_dgrad2_bnred: null hooks");
+  return conv_dgrad2_impl(dy, w, dx, skip, ldskip, hooks, workspace, workspace_bytes, d, stream, "mmi_conv_dgrad2_bnred");
 }
 
 namespace {

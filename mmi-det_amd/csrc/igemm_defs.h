@@ -63,6 +63,15 @@ struct IgemmP {
   // pre-split operands (igemm_kernel<..., T8>, t8.hip): the T8 images of A and / or B (same element indexing, 6 bytes per element)
   const void* A8;
   const void* B8;
+  // dgrad only (mmi_conv_dgrad_bnred*, round 4): the output dx IS the incoming gradient of the BatchNorm + activation whose output the
+  // convolution read, so the epilogue -- which holds the finished dx tile -- takes that BatchNorm's backward REDUCTION along:
+  // dz = dx * act'(xhat * gamma + beta), partial column sums of dz and dz * xhat per row block into stat_part[mtile][2][Ncol]
+  // (the layout mmi_bn_act_bwd_apply folds).  bnr_y: the BatchNorm's input (that layer's raw conv output), row stride bnr_ldy;
+  // mean / invstd through bn_mi / mi_stride; null = off.
+  const float* bnr_y;
+  const float* bnr_g;
+  const float* bnr_b;
+  int bnr_ldy, bnr_act;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -98,6 +107,7 @@ struct WgradP {
 // the loaders' address parts scalar -- and with them 10-20 % of the dgrad / wgrad kernels' speed: profiles/r03_twin_param_select.txt.)
 struct IgemmDelta {
   int64_t A, B, C, stat_part, sk_slots, sk_count, aux, aux_out, fold_part, fold_l1, fold_cnt, bn_mi, bn_rmean, bn_rvar, bn_nbt, A8, B8;
+  int64_t bnr_y, bnr_g, bnr_b;
 };
 struct WgradDelta {
   int64_t DY, X, OUT, OUTB, cnt, DW, DB, DY8, X8;

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
     p.bn_mi = shift_ptr(p.bn_mi, dz.bn_mi); p.bn_rmean = shift_ptr(p.bn_rmean, dz.bn_rmean); p.bn_rvar = shift_ptr(p.bn_rvar, dz.bn_rvar);
     p.bn_nbt = shift_ptr(p.bn_nbt, dz.bn_nbt);
     p.A8 = shift_ptr(p.A8, dz.A8); p.B8 = shift_ptr(p.B8, dz.B8);
+    if constexpr (DGRAD) {
+      p.bnr_y = shift_ptr(p.bnr_y, dz.bnr_y); p.bnr_g = shift_ptr(p.bnr_g, dz.bnr_g); p.bnr_b = shift_ptr(p.bnr_b, dz.bnr_b);
+    }
   }
   static_assert(!PF2 || (VEC && UNI), "deep prefetch: a form of the uniform-tap loaders");
   constexpr int NSTG = PF2 ? 2 : MMI_IGEMM_STAGES, NS = PF2 ? 2 : 1;   // LDS stages, register sets of staged slabs
@@ -804,7 +807,9 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
     // Interior tiles of the plain training epilogue (bias / BN statistics only): every store is a buffer store whose row
     // displacement is a scalar, so an element costs its statistics (add, fma) and nothing else -- the epilogue runs beside
     // other workgroups' MFMA streams, where VALU instructions are not free (1x1 layers: 4 K slabs per tile).
-    const bool fast_store = UNI && !EPI && !par && p.c_bytes != 0 && p.act == MMI_ACT_NONE && p.res == nullptr &&
+    // (dgrad) the BatchNorm backward reduction of the layer below rides along: see IgemmP::bnr_y
+    const bool bnr = DGRAD && !W41 && p.bnr_y != nullptr;  // uniform
+    const bool fast_store = UNI && !EPI && !par && p.c_bytes != 0 && p.act == MMI_ACT_NONE && p.res == nullptr && !bnr &&
                             m0 + BM <= Mc && n0 + BN <= p.Ncol;  // uniform
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -812,6 +817,10 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
       const bool cok = col < p.Ncol;
       const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
       float s1 = 0.f, s2 = 0.f;
+      float bn_m = 0.f, bn_is = 0.f, bn_g = 0.f, bn_b = 0.f, r1 = 0.f, r2 = 0.f;
+      if (DGRAD && bnr && cok) {
+        bn_m = p.bn_mi[col]; bn_is = p.bn_mi[p.mi_stride + col]; bn_g = p.bnr_g[col]; bn_b = p.bnr_b[col];
+      }
       if (UNI && fast_store) {
         const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
         constexpr int CS = BF ? 2 : 4;   // bytes per output element
@@ -858,7 +867,17 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
             if constexpr (BF) reinterpret_cast<__bf16*>(p.C)[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = (__bf16)v;
             else p.C[(int64_t)(par ? rowmap[lr] : row) * p.ldc + col] = v;
           }
+          if (DGRAD && !BF && bnr && cok && row < Mc) {      // (the arithmetic of bn_bwd_reduce_kernel, on the value just stored)
+            const float xh = (p.bnr_y[(int64_t)row * p.bnr_ldy + col] - bn_m) * bn_is;
+            const float dzv = v * act_grad(xh * bn_g + bn_b, p.bnr_act);
+            r1 += dzv;
+            r2 = __builtin_fmaf(dzv, xh, r2);
+          }
         }
+      }
+      if (DGRAD && bnr) {
+        s1 = r1;
+        s2 = r2;
       }
       if (p.stat_part != nullptr) {  // uniform branch; rows >= M hold exact zeros (zero A rows, no bias with BN)
         s1 += __shfl_xor(s1, 32);

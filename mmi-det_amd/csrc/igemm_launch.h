@@ -115,6 +115,11 @@ int launch_igemm(const IgemmP& p0, const FwdPlan& f, bool vec, void* workspace, 
     q.bn_nbt = ptr_delta(t.bn_nbt, p.bn_nbt);
     q.sk_slots = ptr_delta(t.sk_slots, p.sk_slots); q.sk_count = ptr_delta(t.sk_count, p.sk_count);
     q.A8 = ptr_delta(t.A8, p.A8); q.B8 = ptr_delta(t.B8, p.B8);
+    if ((t.bnr_y == nullptr) != (p.bnr_y == nullptr) || t.bnr_ldy != p.bnr_ldy || t.bnr_act != p.bnr_act) {
+      mmi_set_error("%s: the two problems of a twin launch must agree on the BatchNorm reduction riding along", who);
+      return MMI_ERR_ARG;
+    }
+    q.bnr_y = ptr_delta(t.bnr_y, p.bnr_y); q.bnr_g = ptr_delta(t.bnr_g, p.bnr_g); q.bnr_b = ptr_delta(t.bnr_b, p.bnr_b);
   }
   if (f.sk_grid > 0) {
     if (twin != nullptr) {   // (the caller laid out both problems' counters and slots: igemm.hip, "twin launches")

@@ -39,6 +39,15 @@ class LinearEpilogue(Structure):
 EPI_NONE, EPI_DROPOUT_RESIDUAL, EPI_GELU, EPI_GELU_GRAD, EPI_ACCUMULATE = 0, 1, 2, 3, 4
 
 
+class BnReduceHook(Structure):
+    """mmi_bn_reduce_hook (include/mmidet_hip.h)."""
+    _fields_ = [('y', c_void_p), ('ldy', c_int32), ('mean_invstd', c_void_p), ('mi_stride', c_int32), ('gamma', c_void_p),
+                ('beta', c_void_p), ('act', c_int32), ('partials', c_void_p)]
+
+
+BnReduceHookPair = BnReduceHook * 2
+
+
 class BnMap(Structure):
     """mmi_bn_map (include/mmidet_hip.h): parameter blocks + output scatter of a BatchNorm pass over a multi-module buffer."""
     _fields_ = [('gamma', c_void_p * 4), ('beta', c_void_p * 4), ('dgamma', c_void_p * 4), ('dbeta', c_void_p * 4),
@@ -97,6 +106,12 @@ _SIGS = {
     'mmi_conv_bn_fwd2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(BnStatsPair), c_int, P, c_size_t,
                                  POINTER(ConvDesc), P]),
     'mmi_conv_dgrad2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), c_int, P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad_row_blocks_n': (c_int, [POINTER(ConvDesc), c_int]),
+    'mmi_conv_dgrad_bnred': (c_int, [P, P, P, P, c_int, POINTER(BnReduceHook), P, c_size_t, POINTER(ConvDesc), P]),
+    'mmi_conv_dgrad2_bnred': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), c_int, POINTER(BnReduceHookPair), P,
+                                      c_size_t, POINTER(ConvDesc), P]),
+    'mmi_bn_act_bwd_apply_map': (c_int, [P, c_int, P, c_int, P, c_int, P, POINTER(BnMap), POINTER(PtrPair), c_int, P, c_int, c_int64, c_int,
+                                         c_int, c_int, P]),
     'mmi_conv_wgrad2': (c_int, [POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), POINTER(PtrPair), P, c_size_t, P, POINTER(ConvDesc), P]),
     'mmi_bn_finalize': (c_int, [P, c_int, c_int64, c_int, c_float, c_float, P, P, P, P, P]),
     'mmi_bn_eval_stats': (c_int, [P, P, c_int, c_float, P, P]),
@@ -189,7 +204,7 @@ _SIGS = {
     'mmi_detect_loss': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int64, P, c_float, c_float, c_float,
                                 c_float, c_float, c_float, P, c_int, c_float, c_int, P, c_size_t, P, P]),
 }
-_UNCHECKED = ('mmi_version', 'mmi_cem_blocks', 'mmi_cem_conv2_fwd_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
+_UNCHECKED = ('mmi_version', 'mmi_conv_dgrad_row_blocks_n', 'mmi_cem_blocks', 'mmi_cem_conv2_fwd_blocks', 'mmi_cem_bwd_mid_blocks', 'mmi_conv_fwd_row_blocks_bf16', 'mmi_comm_available', 'mmi_comm_world', 'mmi_comm_rank', 'mmi_conv_fwd_row_blocks', 'mmi_conv_fwd_row_blocks_n', 'mmi_set_streamk_slots', 'mmi_set_uniform_loaders', 'mmi_set_deep_prefetch', 'mmi_bn_bwd_parts', 'mmi_layernorm_bwd_parts')
 
 EXPORTS = sorted(_SIGS)
 

@@ -115,6 +115,18 @@ def conv_dgrad(dy, w, dx, d, s):
     lib.conv_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr() if nb else None, nb, d, s)
 
 
+def conv_dgrad_bnred(dy, w, dx, d, hook, s, skip=None, lds=0):
+    """conv_dgrad with the BatchNorm backward reduction of the layer below in its epilogue (lib.BnReduceHook; include/mmidet_hip.h);
+    skip: rows tensor added in the epilogue (1x1 stride-1 layers)."""
+    k = _desc_key(d)
+    nb = _dgrad_ws.get(k)
+    if nb is None:
+        nb = _dgrad_ws[k] = lib.conv_dgrad_workspace(d)
+    ws = zeroed_scratch(nb, dy.device, s) if nb else None
+    lib.conv_dgrad_bnred(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), skip.data_ptr() if skip is not None else None, lds, hook,
+                         ws.data_ptr() if nb else None, nb, d, s)
+
+
 def rows_of(t):
     """Return (tensor, ld): `tensor` is `t` (or a compacted copy) viewed as rows x C with unit channel stride and a
     uniform row stride ld."""

@@ -132,6 +132,49 @@ def dgrad2(dy, cout, wa, wb, dx, d, skip=None, s=None):
                         cin, s)
 
 
+def dgrad2_bnred(dy, cout, wa, wb, dx, d, y, mi, gammas, betas, act, skip=None, s=None):
+    """dgrad2 with both lanes' BatchNorm backward reductions in the epilogue (include/mmidet_hip.h: mmi_conv_dgrad2_bnred).  y
+    (N,H,W,2,Cin) dense: the raw conv output of the layer below, mi its (2, 2*Cin) mean | invstd, gammas / betas its two modules'.
+    Returns (partials (2, nparts, 2, Cin), nparts), or None where the form does not exist (stride-2 layers, a skip that cannot be
+    added in the epilogue, bf16 storage) -- nothing has been launched then."""
+    cin = dx.shape[4]
+    if dy.dtype != torch.float32 or d.stride != 1 or (d.KH != 1 and d.KH != 3):
+        return None
+    dd = ConvDesc(d.N, d.H, d.W, cin, d.Ho, d.Wo, cout, d.KH, d.KW, d.stride, d.pad, 2 * cin, 2 * cout)
+    sp, lds = None, 0
+    if skip is not None:
+        lds, lss = layout(skip)
+        if not (d.KH == 1 and cin % 4 == 0 and cout % 4 == 0 and lds % 4 == 0 and lss % 4 == 0 and skip.data_ptr() % 16 == 0):
+            return None
+        sp = lib.ptr_pair(skip.data_ptr(), skip.data_ptr() + 4 * lss)
+    key = ('d',) + ops._desc_key(dd)
+    nb = _plan.get(key)
+    if nb is None:
+        nb = _plan[key] = lib.conv_dgrad_workspace_n(dd, 2)
+    kb = ('db',) + ops._desc_key(dd)
+    nparts = _plan.get(kb)
+    if nparts is None:
+        nparts = _plan[kb] = lib.conv_dgrad_row_blocks_n(dd, 2)
+    ws = _ws(nb, dy.device, s, 'twin')
+    parts = alloc.empty((2, nparts, 2, cin), dtype=torch.float32, device=dy.device)
+    hooks = lib.BnReduceHookPair()
+    for g in range(2):
+        hooks[g] = lib.BnReduceHook(y.data_ptr() + 4 * g * cin, 2 * cin, mi.data_ptr() + 4 * g * cin, 2 * cin, gammas[g].data_ptr(),
+                                    betas[g].data_ptr(), act, parts[g].data_ptr())
+    dyp = lib.ptr_pair(dy.data_ptr(), dy.data_ptr() + 4 * cout)
+    dxp = lib.ptr_pair(dx.data_ptr(), dx.data_ptr() + 4 * cin)
+    lib.conv_dgrad2_bnred(dyp, _pair(wa, wb), dxp, sp, lds, hooks, _aligned(ws) if ws is not None else None, nb, dd, s)
+    return parts, nparts
+
+
+def bn_apply_map(y, dout, mi, m, parts, dy, rows, c, act, frozen, s):
+    """The apply pass of a twin BatchNorm backward whose reduction came out of dgrad2_bnred (parts = its return value)."""
+    p, nparts = parts
+    ldd, _ = layout(dout)
+    lib.bn_act_bwd_apply_map(y.data_ptr(), c, dout.data_ptr(), ldd, None, 0, mi.data_ptr(), m, lib.ptr_pair(p[0].data_ptr(), p[1].data_ptr()),
+                             nparts, dy.data_ptr(), c, rows, c, act, frozen, s)
+
+
 def wgrad2(dy, dy_off, lddy, lsdy, x, ldx, lsx, wa, wb, cout, k, stride, shape, overlap, out=None):
     """(dwa, dwb) = dy_g^T x_g for both lanes in one launch, on the wgrad side stream when overlap (ops._wgrad's conventions:
     deferred join keeps the operands alive).  out = (dwa, dwb): caller-owned outputs of cout rows each (packed parameters)."""
