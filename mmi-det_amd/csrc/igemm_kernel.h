@@ -869,7 +869,17 @@ __global__ __launch_bounds__(256, (!PF2 && MMI_IGEMM_STAGES == 1 && BK == 32 && 
           }
           if (DGRAD && !BF && bnr && cok && row < Mc) {      // (the arithmetic of bn_bwd_reduce_kernel, on the value just stored)
             const float xh = (p.bnr_y[(int64_t)row * p.bnr_ldy + col] - bn_m) * bn_is;
-            const float dzv = v * act_grad(xh * bn_g + bn_b, p.bnr_act);
+            // (SiLU' with the hardware exp / reciprocal: one ulp each, where act_grad's expf and IEEE division are ~20 instructions
+            //  per element of an epilogue that runs beside other workgroups' MFMA streams)
+            const float zv = xh * bn_g + bn_b;
+            float ag = 1.0f;
+            if (p.bnr_act == MMI_ACT_SILU) {
+              const float sg = __frcp_rn(1.0f + __expf(-zv));
+              ag = sg * (1.0f + zv * (1.0f - sg));
+            } else if (p.bnr_act == MMI_ACT_LEAKY) {
+              ag = zv > 0.f ? 1.0f : 0.1f;
+            }
+            const float dzv = v * ag;
             r1 += dzv;
             r2 = __builtin_fmaf(dzv, xh, r2);
           }

@@ -488,6 +488,54 @@ def _dgrad_accumulate(dy, w, dx, d, dd, skip, s):
         lib.add(dx.data_ptr(), d.Cin, skip.data_ptr(), lds, dx.data_ptr(), d.Cin, _nrows(dx), d.Cin, s)
 
 
+# The BatchNorm backward REDUCTION of a layer can ride in the epilogue of the dgrad that produces its incoming gradient (csrc/
+# igemm_kernel.h, IgemmP::bnr_y; profiles/r04_bn_pass_knockout.txt: the separate pass costs ~6 ms of the 118 ms step).  Built,
+# verified (tests/test_bnred_gpu.py) and measured SLOWER than the pass it removes -- step +2.2 ms with the 3x3 layers' dgrads
+# carrying it, +5.5 ms with the 1x1 layers' too (profiles/r04_bnred_step_ab.txt): in the MFMA accumulator layout a lane owns one
+# column of four rows, so y arrives as 4-byte loads and the 15-20 VALU instructions per element sit in an epilogue that the other
+# workgroups' MFMA streams do not hide.  OFF by default ("1": on).
+BNRED = __import__("os").environ.get("MMIDET_BNRED", "0") == "1"
+BNRED_COUNT = {'taken': 0, 'rejected': 0}      # (tests / diagnostics)
+# ... in the dgrad of 1x1 layers too ("1"): their tiles have 4-8 K slabs, the added epilogue work is as long as the whole K loop
+BNRED_K1 = __import__("os").environ.get("MMIDET_BNRED_K1", "0") == "1"
+
+
+class BnSrc:
+    """What a consumer's dgrad needs to know about the Conv+BatchNorm+activation layer whose OUTPUT it differentiates, hung on that
+    output tensor (`t._bnsrc`) by the producer's forward.  uses: hook-aware consumers seen in forward.  The consumer's backward leaves
+    parts = (partials, nparts) and the identity of the gradient tensor it wrote (address, version counter); the producer's backward
+    takes the short form only if the gradient it receives IS that tensor, unmodified -- any other reader of the output makes autograd
+    hand over a sum (another tensor, or the same one with a bumped version), and the full reduction runs as before."""
+    __slots__ = ('y', 'mi', 'gammas', 'betas', 'act', 'twin', 'uses', 'parts', 'dx_ptr', 'dx_version')
+
+    def __init__(self, y, mi, gammas, betas, act, twin):
+        self.y, self.mi, self.gammas, self.betas, self.act, self.twin = y, mi, gammas, betas, act, twin
+        self.uses, self.parts, self.dx_ptr, self.dx_version = 0, None, 0, -1
+
+    def wrote(self, dx, parts):
+        self.parts, self.dx_ptr, self.dx_version = parts, dx.data_ptr(), dx._version
+
+    def take(self, dout):
+        """The partial sums, if `dout` is the tensor they were taken from; they are consumed either way."""
+        parts, self.parts = self.parts, None
+        if parts is None:
+            return None
+        if dout.data_ptr() == self.dx_ptr and dout._version == self.dx_version and dout.is_contiguous():
+            BNRED_COUNT['taken'] += 1
+            return parts
+        BNRED_COUNT['rejected'] += 1      # (correct, but the epilogue's work was wasted: another reader of the output exists)
+        return None
+
+
+def bn_src_of(x, twin):
+    """The BnSrc of a forward input, counted as used -- or None (no source, grad mode off, the feature off, layouts differ)."""
+    src = getattr(x, '_bnsrc', None) if BNRED else None
+    if src is None or src.twin != twin or x.dtype != torch.float32:
+        return None
+    src.uses += 1
+    return src
+
+
 class _ConvBnAct(Function):
     """act(BN(conv(x))) [+ residual]; training-mode BN statistics are finished inside the conv launch.
     skip=True also returns x itself as a second output: a Bottleneck hands that to its second conv as the residual, so the
@@ -514,6 +562,10 @@ class _ConvBnAct(Function):
         _bn_act_fwd(y, cout, mi, gamma, beta, residual, ldr, out, ldo, None, 0, cout, rows, cout, act, s)
         ctx.save_for_backward(x, w, y, mi, gamma, beta)
         ctx.cfg = (d, act, training, residual is not None, skip)
+        ctx.src_in = bn_src_of(x_in, False) if ctx.needs_input_grad[0] else None
+        ctx.src_out = None
+        if BNRED and dest is None and y.dtype == torch.float32 and any(ctx.needs_input_grad):
+            ctx.src_out = out._bnsrc = BnSrc(y, mi, (gamma,), (beta,), act, False)
         return (out, x_in) if skip else out
 
     @staticmethod
@@ -527,15 +579,36 @@ class _ConvBnAct(Function):
         dy = alloc.empty_like(y)
         dgamma = grad_like(gamma)
         dbeta = grad_like(beta)
-        _bn_act_bwd(y, cout, dout, ldd, None, 0, cout, mi, gamma, beta, dy, (dgamma, dbeta, None, None), rows, cout, act,
-                    0 if training else 1, s)
+        parts = ctx.src_out.take(dout) if ctx.src_out is not None and ldd == cout else None
+        if parts is not None:        # the reduction came out of the consumer's dgrad epilogue: fold + apply
+            lib.bn_act_bwd_apply(y.data_ptr(), cout, dout.data_ptr(), ldd, mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(), parts[0].data_ptr(),
+                                 parts[1], dy.data_ptr(), cout, dgamma.data_ptr(), dbeta.data_ptr(), rows, cout, act, 0 if training else 1, s)
+        else:
+            _bn_act_bwd(y, cout, dout, ldd, None, 0, cout, mi, gamma, beta, dy, (dgamma, dbeta, None, None), rows, cout, act,
+                        0 if training else 1, s)
         dx = None
         both = OVERLAP_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         dw = _wgrad(dy, cout, x, d.ldx, w, d, overlap=both) if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
             dx = alloc.empty((d.N, d.H, d.W, d.Cin), dtype=x.dtype, device=x.device)
             dd = ConvDesc(d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.KH, d.KW, d.stride, d.pad, d.Cin, cout)
+            src, sk, lds = ctx.src_in, None, 0
             if skip and dskip is not None:
+                sk, lds = rows_of(dskip)
+            ok = (src is not None and src.uses == 1 and d.stride == 1 and (d.KH == 3 or (d.KH == 1 and BNRED_K1)) and d.ldx == d.Cin and d.Cin % 4 == 0 and cout % 4 == 0
+                  and d.Cin >= 32 and cout >= 32 and           # (not the CEM's direct 3 / 24-channel convolutions)
+                  (sk is None or (d.KH == 1 and lds % 4 == 0 and sk.dtype == torch.float32 and sk.data_ptr() % 16 == 0)))
+            if ok:
+                kb = ('dgb',) + _desc_key(dd)
+                nparts = _dgrad_ws.get(kb)
+                if nparts is None:
+                    nparts = _dgrad_ws[kb] = lib.conv_dgrad_row_blocks_n(dd, 1)
+                part = alloc.empty((nparts, 2, d.Cin), dtype=torch.float32, device=x.device)
+                hook = lib.BnReduceHook(src.y.data_ptr(), d.Cin, src.mi.data_ptr(), d.Cin, src.gammas[0].data_ptr(), src.betas[0].data_ptr(),
+                                        src.act, part.data_ptr())
+                conv_dgrad_bnred(dy, w, dx, dd, hook, s, skip=sk, lds=lds)
+                src.wrote(dx, (part, nparts))
+            elif skip and dskip is not None:
                 _dgrad_accumulate(dy, w, dx, d, dd, dskip, s)
             else:
                 _conv_dgrad_any(dy, w, dx, dd, s)

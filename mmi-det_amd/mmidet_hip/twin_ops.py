@@ -138,7 +138,7 @@ def dgrad2_bnred(dy, cout, wa, wb, dx, d, y, mi, gammas, betas, act, skip=None, 
     Returns (partials (2, nparts, 2, Cin), nparts), or None where the form does not exist (stride-2 layers, a skip that cannot be
     added in the epilogue, bf16 storage) -- nothing has been launched then."""
     cin = dx.shape[4]
-    if dy.dtype != torch.float32 or d.stride != 1 or (d.KH != 1 and d.KH != 3):
+    if dy.dtype != torch.float32 or d.stride != 1 or not (d.KH == 3 or (d.KH == 1 and ops.BNRED_K1)):
         return None
     dd = ConvDesc(d.N, d.H, d.W, cin, d.Ho, d.Wo, cout, d.KH, d.KW, d.stride, d.pad, 2 * cin, 2 * cout)
     sp, lds = None, 0
@@ -250,6 +250,10 @@ class _TwinConvBnAct(Function):
                            out.data_ptr(), ldo, None, 0, rows, 2 * cout, act, s)
         ctx.save_for_backward(x, wa, wb, y, mi, ga, ba, gb, bb)
         ctx.cfg = (d, act, training, residual is not None, skip, k, stride)
+        ctx.src_in = ops.bn_src_of(x_in, True) if ctx.needs_input_grad[0] else None
+        ctx.src_out = None
+        if ops.BNRED and dest is None and y.dtype == torch.float32 and any(ctx.needs_input_grad):
+            ctx.src_out = out._bnsrc = ops.BnSrc(y, mi, (ga, gb), (ba, bb), act, True)
         return (out, x_in) if skip else out
 
     @staticmethod
@@ -267,10 +271,14 @@ class _TwinConvBnAct(Function):
         dgs = (grad_like(ga), grad_like(gb))
         dbs = (grad_like(ba), grad_like(bb))
         m = _bn_map((ga, gb), (ba, bb), cout, cout, cout, lsd, 0, dgs, dbs)
-        nbw = ops.bn_bwd_ws(rows, 2 * cout)
-        ws = zeroed_scratch(nbw, y.device, s, tag='bn')
-        lib.bn_act_bwd_map(y.data_ptr(), 2 * cout, dout.data_ptr(), ldd, None, 0, mi.data_ptr(), m, ws.data_ptr(), nbw, dy.data_ptr(),
-                           2 * cout, rows, 2 * cout, act, 0 if training else 1, s)
+        parts = ctx.src_out.take(dout) if ctx.src_out is not None and ldd == 2 * cout and lsd == cout else None
+        if parts is not None:        # both lanes' reductions came out of the consumer's dgrad epilogue: fold + apply
+            bn_apply_map(y, dout, mi, m, parts, dy, rows, 2 * cout, act, 0 if training else 1, s)
+        else:
+            nbw = ops.bn_bwd_ws(rows, 2 * cout)
+            ws = zeroed_scratch(nbw, y.device, s, tag='bn')
+            lib.bn_act_bwd_map(y.data_ptr(), 2 * cout, dout.data_ptr(), ldd, None, 0, mi.data_ptr(), m, ws.data_ptr(), nbw, dy.data_ptr(),
+                               2 * cout, rows, 2 * cout, act, 0 if training else 1, s)
         need_x = ctx.needs_input_grad[0]
         both = ops.OVERLAP_WGRAD and need_x
         dwa = dwb = None
@@ -279,7 +287,13 @@ class _TwinConvBnAct(Function):
         dx = None
         if need_x:
             dx = alloc.empty((n, h, w, 2, cin), dtype=x.dtype, device=x.device)
-            dgrad2(dy, cout, wa, wb, dx, d, dskip if skip else None, s)
+            src, done = ctx.src_in, None
+            if src is not None and src.uses == 1 and lsx == cin and ldx == 2 * cin and cin % 4 == 0 and cout % 4 == 0:
+                done = dgrad2_bnred(dy, cout, wa, wb, dx, d, src.y, src.mi, src.gammas, src.betas, src.act, dskip if skip else None, s)
+                if done is not None:
+                    src.wrote(dx, done)
+            if done is None:
+                dgrad2(dy, cout, wa, wb, dx, d, dskip if skip else None, s)
         if both:
             ops._join_side(x.device)
         return (dx, dwa, dwb, dgs[0], dbs[0], dgs[1], dbs[1], None, None, None, None, None, None, (dout if has_res else None), None,

@@ -112,3 +112,33 @@ def test_twin_dgrad_with_both_lanes_reductions(shape, skip):
         close(dg1[i], dg0[i], what='dgamma lane %d' % i, tol=2e-5)
         close(db1[i], db0[i], what='dbeta lane %d' % i, tol=2e-5)
     close(dyb1, dyb0, what='dy of the BatchNorm', tol=2e-5)
+
+
+@pytest.mark.parametrize('kind', ['fourier', 'add'])
+def test_training_step_takes_the_fused_reduction_and_matches_the_separate_pass(kind, monkeypatch):
+    """Whole model (tiny two-stream graphs, twin and lane layers, Bottleneck shortcuts, C3 concatenations): with the feature on, the
+    BatchNorm backward of every layer whose output has exactly one (hook-aware) reader takes its sums from that reader's dgrad
+    epilogue -- and every parameter gradient equals the run with the feature off to summation-order rounding.  No epilogue's work
+    is thrown away ('rejected' = a consumer computed sums for a gradient that turned out not to be the whole one)."""
+    import copy
+    from mmidet_hip import ops
+    from test_step_gpu import batch, make
+    grads = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, 'BNRED', on)
+        ops.BNRED_COUNT.update(taken=0, rejected=0)
+        torch.manual_seed(0)
+        m, ts, cfg = make(kind)
+        imgs, tg = batch(cfg, 77)
+        ts._body(imgs, tg)                 # forward, loss, backward (no optimizer step: the gradients are what is compared)
+        ops.join_pending()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        counts = copy.copy(ops.BNRED_COUNT)
+    assert counts['taken'] >= 8 and counts['rejected'] == 0, counts
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 50
+    for n in grads[0]:
+        if float(grads[0][n].abs().max()) < 1e-7:      # (key_proj.bias: its gradient is zero mathematically, rounding noise in fp32)
+            continue
+        close(grads[1][n], grads[0][n], what=n, tol=5e-4)
+    print('BatchNorm reductions taken from a dgrad epilogue:', counts)
