@@ -207,6 +207,17 @@ def hbm_ops(model, bs, size, dev):
         model.Enhance.eval()                     # (eval: the timing must not move the BatchNorm running statistics)
         row('CEM forward (3 reads + 1 write of x; 24-ch intermediates are the excess)', 4 * img.numel() * 4, lambda: model.Enhance(img))
         model.Enhance.train(was)
+    if was and any(p.requires_grad for p in model.Enhance.parameters()):
+        # the TRAINING forward writes what the backward reads (y2, t: 24 channels each; the channel-sum map) besides y3 and the output, and
+        # moves the BatchNorm running statistics: restored afterwards
+        keep = {k: v.clone() for k, v in model.Enhance.state_dict().items() if 'running' in k or 'tracked' in k}
+        px = img.numel() // 3
+        # (algorithmic: x read; y2, t, chansum, y3 written; BatchNorm3 + residual pass: y3, x read, out written -- the second launch's
+        #  re-read of y2 is the implementation's, not the algorithm's)
+        row('CEM training forward (y2, t, chansum kept for the backward; y3, out written)', px * 4 * (3 + 24 + 24 + 1 + 3 + 3 + 3 + 3),
+            lambda: model.Enhance(img))
+        model.Enhance.load_state_dict({**model.Enhance.state_dict(), **keep})
+    with torch.no_grad():
         mi = torch.cat([torch.zeros(c2, device=dev), torch.ones(c2, device=dev)])
         g1, b1 = torch.ones(c2, device=dev), torch.zeros(c2, device=dev)
         o = torch.empty_like(a)

@@ -207,7 +207,7 @@ int mmi_bn_act_bwd_reduce(const float* y, int ldy, const float* dout, int ldd, c
                           const float* gamma, const float* beta, float* partials, int64_t rows, int C, int act,
                           void* stream);
 /* backward, pass 2: sums partials -> dgamma,dbeta (C each) and writes dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).
- * In eval-stat mode (frozen=1) dy = gamma*invstd*dz. */
+ * In eval-stat mode (frozen=1) dy = gamma*invstd*dz.  dy = NULL: the fold only (dgamma, dbeta). */
 int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, int ldd, const float* mean_invstd,
                          const float* gamma, const float* beta, const float* partials, int nparts, float* dy, int lddy,
                          float* dgamma, float* dbeta, int64_t rows, int C, int act, int frozen, void* stream);

@@ -631,11 +631,12 @@ extern "C" int mmi_bn_act_bwd_apply(const float* y, int ldy, const float* dout, 
                                     const float* gamma, const float* beta, const float* partials, int nparts, float* dy,
                                     int lddy, float* dgamma, float* dbeta, int64_t rows, int C, int act, int frozen,
                                     void* stream) {
-  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && dy && dgamma && dbeta && rows > 0 && C > 0,
-                "mmi_bn_act_bwd_apply: bad arguments");
+  MMI_CHECK_ARG(y && dout && mean_invstd && gamma && beta && partials && dgamma && dbeta && rows > 0 && C > 0,
+                "mmi_bn_act_bwd_apply: bad arguments");      // (dy == NULL: the fold only)
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partials, nparts, C, dgamma, dbeta, 1);
   MMI_CHECK_LAUNCH("mmi_bn_act_bwd_apply(finalize)");
+  if (dy == nullptr) return MMI_OK;
   const mmi_bn_map mp = plain_map(gamma, beta, dgamma, dbeta, nullptr, nullptr, C, C);
   return launch_apply<float>(y, ldy, dout, ldd, nullptr, 0, mean_invstd, mp, dy, lddy, rows, C, act, frozen, s);
 }

@@ -1144,9 +1144,12 @@ def sobel_add(r, factor, bias):
 CEM_FUSED = __import__("os").environ.get("MMIDET_CEM_FUSED", "1") != "0"      # A/B: the fused CEM forward
 CEM_WGRAD_LATE = __import__("os").environ.get("MMIDET_CEM_WGRAD_LATE", "0") == "1"   # A/B: conv3's wgrad after the critical chain (no gain)
 CEM_BWD_FUSED = __import__("os").environ.get("MMIDET_CEM_BWD_FUSED", "1") != "0"   # A/B: conv3 dgrad + stencil-bank backward in one kernel
-# ... with BatchNorm2's backward reduction riding along: correct (tests/test_cem_gpu.py) but 48 more accumulators cost the kernel a
-# workgroup per CU (233 VGPRs): 3.69 -> 3.92 ms for the module (profiles/r02_cem_backward_middle.txt).  Off.
-CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "0") == "1"
+# ... with BatchNorm2's backward reduction riding along.  Round 2: 48 more accumulators cost the kernel a workgroup per CU (233 VGPRs)
+# and the module was slower WITH the apply pass still reading dr and y2 (3.69 -> 3.92 ms, profiles/r02_cem_backward_middle.txt).  Round 4:
+# the apply pass lives in conv2's weight-gradient loader, so the reduction pass was the last separate reader of (dr, y2) -- without it
+# the module takes 2.32 instead of 2.42 ms (profiles/r04_cem_bwd_forms.txt; a lower-register form of the kernel's last phase, a thread
+# per (position, 4-channel group), measured the same 2.33 and was dropped).  On.
+CEM_BWD_BN = __import__("os").environ.get("MMIDET_CEM_BWD_BN", "1") != "0"
 # Training forward as conv2 (stored, with BN2's statistics) + the fused kernel reading y2: conv2 evaluated once instead of 2.56 times
 # per pixel; same arithmetic on the same y2 (tests/test_cem_gpu.py).  "0": statistics pre-pass + recomputing fused kernel (rounds 2-3).
 CEM_TWO_PASS = __import__("os").environ.get("MMIDET_CEM_TWO_PASS", "1") != "0"
@@ -1247,12 +1250,16 @@ class _CemFused(Function):
                               ws.data_ptr(), n, h, w, 24, s)
         # BN2 + LeakyReLU
         dg2, db2 = grad_like(g2), grad_like(b2)
-        if CEM_WGRAD_BN and not ctx.needs_input_grad[0] and not (CEM_BWD_FUSED and CEM_BWD_BN):
+        if CEM_WGRAD_BN and not ctx.needs_input_grad[0]:
             # sums only, then the apply pass inside conv2's weight-gradient loader (csrc/cem.hip, BNF)
-            nbw = bn_bwd_ws(rows, 24)
-            ws2 = zeroed_scratch(nbw, dev, s, tag='bn')
-            lib.bn_act_bwd(y2.data_ptr(), 24, dr.data_ptr(), 24, None, 0, 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), ws2.data_ptr(),
-                           nbw, None, 24, dg2.data_ptr(), db2.data_ptr(), None, None, rows, 24, ACT_LEAKY, frozen, s)
+            if CEM_BWD_FUSED and CEM_BWD_BN:      # ... which came out of cem_bwd_mid: fold its partials
+                lib.bn_act_bwd_apply(y2.data_ptr(), 24, dr.data_ptr(), 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), bnpart.data_ptr(),
+                                     lib.cem_bwd_mid_blocks(n, h, w), None, 24, dg2.data_ptr(), db2.data_ptr(), rows, 24, ACT_LEAKY, frozen, s)
+            else:
+                nbw = bn_bwd_ws(rows, 24)
+                ws2 = zeroed_scratch(nbw, dev, s, tag='bn')
+                lib.bn_act_bwd(y2.data_ptr(), 24, dr.data_ptr(), 24, None, 0, 24, mi2.data_ptr(), g2.data_ptr(), b2.data_ptr(), ws2.data_ptr(),
+                               nbw, None, 24, dg2.data_ptr(), db2.data_ptr(), None, None, rows, 24, ACT_LEAKY, frozen, s)
             dw2 = grad_like(w2)
             nb = lib.cem_conv2_wgrad_bn_workspace(n, h, w)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of cem_bwd_mid's grid size within one box (module time, shipped configuration)
+# A/B of the CEM backward forms within one box (module time at 16 x 640 x 640)
 export BENCH_CEM_FUSED_ONLY=1
-for v in 1024 768 512 384 256 1024 512; do
-  echo -n "blocks $v: "
-  MMIDET_CEM_MID_BLOCKS=$v python tools/bench_cem.py 2>&1 | grep "fused forward"
+for v in "MMIDET_CEM_BWD_BN=0" "MMIDET_CEM_BWD_BN=1" "MMIDET_CEM_BWD_BN=0" "MMIDET_CEM_BWD_BN=1"; do
+  echo -n "$v: "
+  env $v python tools/bench_cem.py 2>&1 | grep "fused forward"
 done
