@@ -191,14 +191,19 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+// MMI_FAST_SILU (a build-time A/B): the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: one ulp each)
+// instead of expf and an IEEE division -- ~25 fewer VALU instructions per element in the BatchNorm passes.
+#ifndef MMI_FAST_SILU
+#define MMI_FAST_SILU 0
+#endif
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == MMI_ACT_SILU) return z / (1.0f + expf(-z));
+  if (act == MMI_ACT_SILU) return MMI_FAST_SILU ? z * __frcp_rn(1.0f + __expf(-z)) : z / (1.0f + expf(-z));
   if (act == MMI_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
   return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == MMI_ACT_SILU) {
-    const float s = 1.0f / (1.0f + expf(-z));
+    const float s = MMI_FAST_SILU ? __frcp_rn(1.0f + __expf(-z)) : 1.0f / (1.0f + expf(-z));
     return s * (1.0f + z * (1.0f - s));
   }
   if (act == MMI_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;

@@ -7,7 +7,11 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')
 LIB = os.path.join(CSRC, 'libmmidet_hip.so')
 # integer/bit-exact kernels must not be FMA-contracted (utils/loss.py:189-245 parity)
-FLAGS = {'targets.hip': ['-ffp-contract=off']}
+# bn.hip: SiLU / SiLU' of the BatchNorm passes on the hardware exp2 / reciprocal (csrc/common.h::MMI_FAST_SILU; one ulp each, the
+# parity bound is 1e-3): 25 fewer VALU instructions per element in kernels that run beside the GEMMs -- step 120.10 -> 119.34 ms
+# (profiles/r04_fast_silu_step_ab.txt); MMIDET_FAST_SILU=0 at build time keeps expf and the IEEE division
+FLAGS = {'targets.hip': ['-ffp-contract=off'],
+         'bn.hip': [] if os.environ.get('MMIDET_FAST_SILU') == '0' else ['-DMMI_FAST_SILU=1']}
 
 
 def build(force=False, verbose=True):
