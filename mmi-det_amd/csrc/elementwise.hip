@@ -544,7 +544,14 @@ extern "C" int mmi_spp_pool_bwd(const float* x, int ldx, const float* dcat, int 
   const int64_t rows = (int64_t)N * H * W;
   {  // tiled form when the map fits in LDS with at least 4 channels per workgroup
     const size_t per_c = (size_t)H * W * SPP_BYTES_PER_ELEM;
-    const int cg = per_c * 16 <= 150 * 1024 ? 16 : (per_c * 8 <= 150 * 1024 ? 8 : (per_c * 4 <= 150 * 1024 ? 4 : 0));
+    // channels per workgroup: 8 = two workgroups per CU at 20 x 20 and all 1024 of them resident at once (16: one per CU, two
+    // rounds).  Backward at 16 x 20 x 20 x 512 (tools/bench_spp.py): 150 us at 16, 117 at 8, 131 at 4.  MMIDET_SPP_BWD_CG: A/B.
+    static const int cg_max = [] {
+      const char* e = getenv("MMIDET_SPP_BWD_CG");
+      const int v = e ? atoi(e) : 8;
+      return v == 4 || v == 16 ? v : 8;
+    }();
+    const int cg = (cg_max >= 16 && per_c * 16 <= 150 * 1024) ? 16 : ((cg_max >= 8 && per_c * 8 <= 150 * 1024) ? 8 : (per_c * 4 <= 150 * 1024 ? 4 : 0));
     if (cg > 0 && W <= 255 && H <= 255) {
       const dim3 grid(cdiv(C, cg), N), block(SPP_THREADS);
       const size_t lds = per_c * cg;
