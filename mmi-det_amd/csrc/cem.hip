@@ -653,6 +653,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // across its tiles: the 48 wave reductions happen once per workgroup, not once per tile (they were 288 ds_bpermute per wave and
 // tile in smallconv_kernel<3, 24>).  Per-position sums keep that kernel's tap-major / channel-minor order: y2 is bit-identical.
 constexpr int C2W = 32, C2H = 16;
+// (two waves per SIMD, 202 VGPRs: capped at 168 for three, the kernel spills 200 B in the channel loop and the training forward goes
+//  from 0.87 to 1.10 ms)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cem_conv2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w2,
                                                             float* __restrict__ y2, float* __restrict__ stat_part, int ldx, int N,
                                                             int H, int W) {

@@ -16,6 +16,8 @@ microseconds per step instead of ~175 ms enqueueing launches.  Graph mode needs 
 """
 import os
 
+import time
+
 import torch
 import torch.nn as nn
 
@@ -384,6 +386,13 @@ class TrainStep:
         # capture error mode that query aborts the process while this thread is capturing.
         native = self.reducer is not None and getattr(self.reducer, 'native', False)
         self._graph_has_collectives = native
+        if self.reducer is not None and not native:
+            # The warm-up steps above issued collectives; the watchdog polls the events of finished ones every 100 ms until it has
+            # retired them.  Such a query from its thread while this thread captures is legal in thread_local mode, yet ONE full
+            # `-m gpu` run of round 4 died with SIGABRT inside the capture of tests/test_step_gpu.py::
+            # test_data_parallel_reducer_corner_cases (no message, autograd thread in a weight-gradient launch; five other runs of
+            # the same code passed).  Let the watchdog finish its list before the capture begins: nothing is in flight afterwards.
+            time.sleep(0.3)
         mode = 'thread_local' if (self.reducer is not None and not native) else 'global'
         with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._loss, self._items = self._body(self._imgs, self._targets, reduce=False)
