@@ -5,7 +5,7 @@ import copy
 import pytest
 import torch
 
-from conftest import tiny_cfg
+from conftest import own_process, tiny_cfg
 from test_ops_gpu import close, dev
 
 pytestmark = pytest.mark.gpu
@@ -186,6 +186,7 @@ def test_padded_targets_are_ignored():
         assert all(torch.equal(u, v) for u, v in zip(a[2][i], b[2][i]))
 
 
+@own_process
 def test_data_parallel_graph_step_matches_whole_step_graph():
     """The N>1 launch structure on one GPU (world size 1, RCCL): forward+backward replayed as a graph, then bucket
     all-reduce and the fused optimizer eagerly -- same losses and weights as the single-GPU whole-step graph."""
@@ -253,6 +254,7 @@ def test_data_parallel_eager_writes_gradients_into_the_buckets():
         dist.destroy_process_group()
 
 
+@own_process
 def test_data_parallel_reducer_corner_cases():
     """(a) gradient accumulation under the reducer, (b) a replayed graph followed by eager steps, (c) the
     collective is ordered behind BOTH lane streams when wgrad runs on them -- each against the single-GPU step, world size 1."""
