@@ -372,6 +372,9 @@ __global__ void sobel_add_fwd_kernel(const float* __restrict__ r, int ldr, const
 // 1 read of x and 1 write each of y2 / t instead of the 4 reads + 4 writes of 24-channel maps of the unfused chain.
 // Positions outside the image contribute zeros exactly where the reference's zero padding puts them (r for the stencils,
 // t for conv3).
+// Round 4: in TRAINING the kernel runs as its FROMY2 form behind cem_conv2_fwd_kernel (conv2 evaluated once, y2 stored with BN2's
+// statistics): phase 1 then reads y2 instead of recomputing it on the halo region.  The recomputing form below stays for inference
+// and for `MMIDET_CEM_TWO_PASS=0`.
 
 // (the read-only operands are separate __restrict__ kernel arguments, not struct members: only then does hipcc fetch the 1300
 //  uniform weights with scalar loads; through a by-value struct they became vector loads held in 256 VGPRs)
