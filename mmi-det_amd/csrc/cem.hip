@@ -658,11 +658,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 constexpr int C2W = 32, C2H = 16;
 // (two waves per SIMD, 202 VGPRs: capped at 168 for three, the kernel spills 200 B in the channel loop and the training forward goes
 //  from 0.87 to 1.10 ms)
+template <bool STAGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cem_conv2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w2,
                                                             float* __restrict__ y2, float* __restrict__ stat_part, int ldx, int N,
                                                             int H, int W) {
   constexpr int XW = C2W + 2, XH = C2H + 2, XN = XW * XH * 3;
+  // STAGE: y2 leaves through LDS as contiguous 3 KB runs.  From registers a position's four channels are one 16-byte store, but the
+  // lanes of a store lie 96 B apart and a position's six groups are stored at six different times: the PMC counted 994 MB written
+  // for 629 MB of y2 (profiles/r04_pmc_cem_module_after.txt).  The kernel runs two workgroups per CU either way (202 VGPRs).
+  constexpr int YP = 28;
   __shared__ float xs[XN];
+  __shared__ __align__(16) float y2s[STAGE ? C2W * C2H * YP : 4];
   __shared__ float red[2][4][24];
   const int t = threadIdx.x, i0 = t >> 5, j = t & 31;
   const int tw = (W + C2W - 1) / C2W, th = (H + C2H - 1) / C2H, ntiles = tw * th * N;
@@ -716,13 +722,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float w = wg[k * 27 + e];
           acc[k] += xin[e] * f32x2{w, w};
         }
-      if (live0) *reinterpret_cast<f32x4*>(dst0 + o0) = f32x4{acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
-      if (live1) *reinterpret_cast<f32x4*>(dst1 + o0) = f32x4{acc[0][1], acc[1][1], acc[2][1], acc[3][1]};
+      if constexpr (STAGE) {
+        *reinterpret_cast<f32x4*>(y2s + t * YP + o0) = f32x4{acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+        *reinterpret_cast<f32x4*>(y2s + (t + 256) * YP + o0) = f32x4{acc[0][1], acc[1][1], acc[2][1], acc[3][1]};
+      } else {
+        if (live0) *reinterpret_cast<f32x4*>(dst0 + o0) = f32x4{acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+        if (live1) *reinterpret_cast<f32x4*>(dst1 + o0) = f32x4{acc[0][1], acc[1][1], acc[2][1], acc[3][1]};
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float m0 = live0 ? acc[k][0] : 0.f, m1 = live1 ? acc[k][1] : 0.f;
         s1[o0 + k] += m0 + m1;
         s2[o0 + k] += m0 * m0 + m1 * m1;
+      }
+    }
+    if constexpr (STAGE) {
+      __syncthreads();
+#pragma unroll
+      for (int e = t; e < C2W * C2H * 6; e += 256) {
+        const int pos = e / 6, g4 = (e - pos * 6) * 4, ih = h0 + pos / C2W, iw = w0 + pos % C2W;
+        if (ih < H && iw < W)
+          *reinterpret_cast<f32x4*>(y2 + (((int64_t)n * H + ih) * W + iw) * 24 + g4) = *reinterpret_cast<const f32x4*>(y2s + pos * YP + g4);
       }
     }
   }
@@ -1205,8 +1225,13 @@ extern "C" int mmi_cem_conv2_fwd(const float* x, int ldx, const float* w2, float
                                  void* stream) {
   MMI_CHECK_ARG(x && w2 && y2 && stat_partials && N > 0 && H > 0 && W > 0 && ldx >= 3, "mmi_cem_conv2_fwd: bad arguments");
   MMI_CHECK_ARG(((uintptr_t)y2 & 15) == 0, "mmi_cem_conv2_fwd: y2 must be 16-byte aligned");
-  hipLaunchKernelGGL(cem_conv2_fwd_kernel, dim3(mmi_cem_conv2_fwd_blocks(N, H, W)), dim3(256), 0, (hipStream_t)stream, x, w2, y2,
-                     stat_partials, ldx, N, H, W);
+  static const bool stage = !(getenv("MMIDET_CEM_C2_STAGE") && atoi(getenv("MMIDET_CEM_C2_STAGE")) == 0);      // A/B switch
+  if (stage)
+    hipLaunchKernelGGL(cem_conv2_fwd_kernel<true>, dim3(mmi_cem_conv2_fwd_blocks(N, H, W)), dim3(256), 0, (hipStream_t)stream, x, w2, y2,
+                       stat_partials, ldx, N, H, W);
+  else
+    hipLaunchKernelGGL(cem_conv2_fwd_kernel<false>, dim3(mmi_cem_conv2_fwd_blocks(N, H, W)), dim3(256), 0, (hipStream_t)stream, x, w2, y2,
+                       stat_partials, ldx, N, H, W);
   MMI_CHECK_LAUNCH("mmi_cem_conv2_fwd");
   return MMI_OK;
 }
