@@ -302,3 +302,39 @@ def test_fused_optimizer_is_a_torch_optimizer_with_sgd_compatible_state():
     ref2.load_state_dict(opt.state_dict())                   # and back
     for p in net.parameters():
         assert torch.equal(ref2.state[p]['momentum_buffer'], ref.state[p]['momentum_buffer'])
+
+
+def test_bn_source_hands_its_sums_only_to_the_untouched_gradient_tensor():
+    """ops.BnSrc (the host side of mmi_conv_dgrad_bnred): the producer may take the partial sums a consumer's dgrad epilogue left only if
+    the gradient it receives IS the tensor that consumer wrote -- same storage address, same version counter, dense.  A second reader
+    of the layer's output makes autograd hand over either another tensor (a sum) or the same one accumulated into in place (version
+    bumped): both must fall back to the full reduction pass.  The sums are consumed either way."""
+    from mmidet_hip import ops
+    src = ops.BnSrc(y=None, mi=None, gammas=(None,), betas=(None,), act=1, twin=False)
+    dx = torch.zeros(2, 4, 4, 8)
+    parts = (torch.zeros(3, 2, 8), 3)
+    before = dict(ops.BNRED_COUNT)
+    src.wrote(dx, parts)
+    assert src.take(dx) is parts and src.parts is None                      # the very tensor
+    assert src.take(dx) is None                                             # consumed: nothing left for a second taker
+    src.wrote(dx, parts)
+    assert src.take(dx.clone()) is None and src.parts is None               # another tensor (autograd summed two gradients)
+    src.wrote(dx, parts)
+    dx.add_(1.0)                                                            # autograd accumulated a second gradient in place
+    assert src.take(dx) is None
+    src.wrote(dx, parts)
+    assert src.take(dx.permute(0, 3, 1, 2)) is None                         # a strided view of it
+    assert ops.BNRED_COUNT['taken'] == before['taken'] + 1 and ops.BNRED_COUNT['rejected'] == before['rejected'] + 3
+    # a consumer only counts itself when the feature is on, the layouts agree and the storage is fp32
+    x = torch.zeros(1, 2, 2, 8)
+    x._bnsrc = ops.BnSrc(None, None, (None,), (None,), 1, twin=False)
+    on = ops.BNRED
+    try:
+        ops.BNRED = False
+        assert ops.bn_src_of(x, False) is None and x._bnsrc.uses == 0
+        ops.BNRED = True
+        assert ops.bn_src_of(x, True) is None and x._bnsrc.uses == 0          # twin consumer of a lane producer
+        assert ops.bn_src_of(x, False) is x._bnsrc and x._bnsrc.uses == 1
+        assert ops.bn_src_of(torch.zeros(1), False) is None                   # no source hung on the tensor
+    finally:
+        ops.BNRED = on
