@@ -338,3 +338,22 @@ def test_bn_source_hands_its_sums_only_to_the_untouched_gradient_tensor():
         assert ops.bn_src_of(torch.zeros(1), False) is None                   # no source hung on the tensor
     finally:
         ops.BNRED = on
+
+
+def test_round4_planning_entry_points_need_no_gpu():
+    """Host-side planners of the round-4 entry points (no device call): grid of the CEM's conv2 kernel (<= 1024 workgroups, equal shares
+    of the 32x16 tiles to within one), workspace of its fused weight gradient, row blocks of a dgrad with the BatchNorm reduction."""
+    from mmidet_hip import lib
+    from mmidet_hip.ops import ConvDesc
+    for n, h, w in ((16, 640, 640), (1, 64, 64), (2, 33, 17), (8, 1280, 1280)):
+        tiles = n * ((h + 15) // 16) * ((w + 31) // 32)
+        g = lib.cem_conv2_fwd_blocks(n, h, w)
+        assert 1 <= g <= min(tiles, 1024)
+        per = -(-tiles // g)
+        assert g * per >= tiles and g * (per - 1) < tiles                 # every workgroup walks `per` or `per - 1` tiles
+        tiles16 = n * ((h + 15) // 16) * ((w + 15) // 16)
+        assert lib.cem_conv2_wgrad_bn_workspace(n, h, w) == min(tiles16, 2048) * 24 * 27 * 4
+    d = ConvDesc(16, 80, 80, 128, 80, 80, 128, 3, 3, 1, 1, 128, 128)
+    nb1, nb2 = lib.conv_dgrad_row_blocks_n(d, 1), lib.conv_dgrad_row_blocks_n(d, 2)
+    assert nb1 >= 16 * 80 * 80 // 128 and nb2 >= 16 * 80 * 80 // 128        # at least M / 128 row blocks (128-row tiles at most)
+    assert nb1 <= 16 * 80 * 80 // 32 and nb2 <= 16 * 80 * 80 // 32
